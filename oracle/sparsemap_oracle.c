@@ -1,0 +1,308 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * fp64 CPU restatement of bit-vector SparseMAP as the reference runs it:
+ *     lvmhelpers/sparsemap.py:12-36    run_sparsemap: eta = [x.double(); 0], optional random init,
+ *                                      solve_qp(max_iter), get_sparse_solution, p[:len(aset)], fp32 out
+ *     lvmhelpers/sparsemap.py:38-44    jv: dist_jacobian_vec, first n entries returned
+ *     lvmhelpers/bernoulli.h:14-35     FactorBernoulli::Maximize (strict >, ties -> off)
+ *     lvmhelpers/bernoulli.h:38-54     Evaluate;  :58-73 UpdateMarginalsFromConfiguration
+ *     lvmhelpers/bernoulli.h:76-109    CountCommonValues / SameConfiguration
+ *     lvmhelpers/budget.h:24-85        FactorBudget::Maximize
+ *
+ * The active-set loop itself (GenericFactor::SolveQP, InvertAfterInsertion/-Removal,
+ * InitActiveSetFromScores, GetSparseSolution, DistJacobianVec) lives in the third-party package
+ * `lpsmap` (github deep-spin/lp-sparsemap, version unpinned: README.md:22; call sites
+ * sparsemap.py:4,15-20,27,29-30,42, pbernoulli.pyx:7, pbudget.pyx:7, setup.py:11,97-99), which is
+ * absent from /root/reference and not installed. This file restates the PUBLISHED AD3 active-set
+ * algorithm (Martins et al. 2015, "AD3", Alg. 3; Niculae et al. 2018, "SparseMAP") from the maths.
+ *
+ * PARITY UNPINNED for the solver path: the reference holds no tests or golden vectors at this
+ * boundary. The optimal marginals are unique, the decomposition into vertices is path dependent;
+ * the choices that fix the path are listed here so the HIP kernel can follow them bit for bit:
+ *   C1  every inner product below is a serial left-to-right fp64 loop, no FMA contraction
+ *       (build with -ffp-contract=off);
+ *   C2  after each change of the active set the KKT system is solved with the cached inverse:
+ *       [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)];
+ *   C3  an iteration that did not change the set computes marginals mu = sum_i z_i cfg_i in
+ *       active-set order, calls the oracle on eta - mu, stops if value <= tau + 1e-9 or if the
+ *       returned configuration is already active, else inserts it;
+ *   C4  insertion: r = [1; common(cfg_i,new)], d = invA r (terms with r_i == 0 skipped),
+ *       s = n - sum_j r_j d_j (serial; upstream uses a triangular double loop -- algebraically
+ *       identical, rounding differs), |s| <= 1e-9 => status SINGULAR and stop (upstream removes a
+ *       null-space configuration via an eigendecomposition; unreachable in exact arithmetic since
+ *       insertion only follows an equality-constrained optimum);
+ *   C5  blocking step and removal as in AD3 (first index wins ties because of the strict <);
+ *   C6  max_iter counts loop passes (solve passes and insert/remove passes alike).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SM_MAX_N 512
+#define SM_WORDS(n) (((n) + 31) / 32)
+
+enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3 };
+
+static inline int bit_of(const uint32_t* cfg, int k) { return (cfg[k >> 5] >> (k & 31)) & 1u; }
+
+/* Linear oracle. on[k], off[k] potentials; fills cfg (W words) and returns the value.
+ * budget <= 0: Bernoulli (bernoulli.h:14-35); budget > 0: budget.h:24-85. */
+static double maximize(const double* on, const double* off, int n, int budget, uint32_t* cfg,
+                       double* e_tmp, int* idx_tmp)
+{
+    const int W = SM_WORDS(n);
+    memset(cfg, 0, sizeof(uint32_t) * (size_t)W);
+    if (budget <= 0) {
+        double value = 0.0;
+        for (int i = 0; i < n; ++i) {
+            if (on[i] > off[i]) { cfg[i >> 5] |= 1u << (i & 31); value += on[i]; }
+            else value += off[i];
+        }
+        return value;
+    }
+    double value = 0.0;
+    for (int i = 0; i < n; ++i) { e_tmp[i] = on[i] - off[i]; value += off[i]; }
+    int num_active = 0;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (e_tmp[i] > 0) { sum += e_tmp[i]; cfg[i >> 5] |= 1u << (i & 31); ++num_active; }
+    if (num_active > budget) {
+        /* sort (-e, i) ascending == e descending, ties by smaller index (pairs are distinct so
+         * std::sort's result is unique): insertion sort is enough for n <= 512 */
+        for (int i = 0; i < n; ++i) idx_tmp[i] = i;
+        for (int i = 1; i < n; ++i) {
+            int v = idx_tmp[i];
+            int j = i - 1;
+            while (j >= 0) {
+                int u = idx_tmp[j];
+                double a = -e_tmp[u], b = -e_tmp[v];
+                int u_before_v = (a < b) || (!(b < a) && u < v);
+                if (u_before_v) break;
+                idx_tmp[j + 1] = u;
+                --j;
+            }
+            idx_tmp[j + 1] = v;
+        }
+        num_active = 0;
+        sum = 0.0;
+        for (int k = 0; k < budget; ++k) {
+            double valaux = e_tmp[idx_tmp[k]]; /* = -scores[k].first */
+            if (valaux < 0) break;
+            int i = idx_tmp[k];
+            cfg[i >> 5] |= 1u << (i & 31);
+            sum += valaux;
+            ++num_active;
+        }
+        for (int k = num_active; k < n; ++k) {
+            int i = idx_tmp[k];
+            cfg[i >> 5] &= ~(1u << (i & 31));
+        }
+    }
+    return value + sum;
+}
+
+static int common_values(const uint32_t* a, const uint32_t* b, int n)
+{
+    int diff = 0;
+    for (int w = 0; w < SM_WORDS(n); ++w) diff += __builtin_popcount(a[w] ^ b[w]);
+    return n - diff;
+}
+
+/*
+ * scores[B,n] fp32; init_scores[B,2n] fp64 or NULL (torch.rand(2n, dtype=double) per sample,
+ * sparsemap.py:25-27); budget 0 => Bernoulli.
+ * Outputs (cap = n+1, W = ceil(n/32), ld = cap+1):
+ *   aset_bits[B,cap,W] u32   active configurations, bit k of word k/32 = variable k on
+ *   p[B,cap] f32             distribution_[:len(aset)] cast to fp32 (rest 0)
+ *   p64[B,cap] f64           same in fp64 (nullable)
+ *   alen[B]                  len(aset)
+ *   invA[B,ld,ld] f64        cached inverse KKT matrix, rows/cols 0..alen meaningful (nullable)
+ *   iters[B]                 loop passes used (nullable);  status[B] (nullable)
+ */
+int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
+                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                         double* p64, int32_t* alen, double* invA_out, int32_t* iters,
+                         int32_t* status)
+{
+    if (n < 1 || n > SM_MAX_N) return -2;
+    const int cap = n + 1, W = SM_WORDS(n), ld = cap + 1;
+    double* eta = (double*)malloc(sizeof(double) * (size_t)n);
+    double* zero = (double*)calloc((size_t)n, sizeof(double));
+    double* mu_on = (double*)malloc(sizeof(double) * (size_t)n);
+    double* mu_off = (double*)malloc(sizeof(double) * (size_t)n);
+    double* e_tmp = (double*)malloc(sizeof(double) * (size_t)n);
+    int* idx_tmp = (int*)malloc(sizeof(int) * (size_t)n);
+    double* A = (double*)malloc(sizeof(double) * (size_t)ld * ld);
+    double* A2 = (double*)malloc(sizeof(double) * (size_t)ld * ld);
+    double* z = (double*)malloc(sizeof(double) * (size_t)ld);
+    double* dist = (double*)malloc(sizeof(double) * (size_t)ld);
+    double* bvec = (double*)malloc(sizeof(double) * (size_t)ld);
+    double* r = (double*)malloc(sizeof(double) * (size_t)ld);
+    double* d = (double*)malloc(sizeof(double) * (size_t)ld);
+    uint32_t* cfg = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap * W);
+    uint32_t* newc = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W);
+
+    for (int64_t s_ = 0; s_ < B; ++s_) {
+        for (int i = 0; i < n; ++i) eta[i] = (double)scores[s_ * n + i];
+        int m = 0;
+        if (init_scores) /* InitActiveSetFromScores: Maximize(init) */
+            maximize(init_scores + s_ * 2 * n, init_scores + s_ * 2 * n + n, n, budget, cfg, e_tmp, idx_tmp);
+        else /* SolveQP with empty active set: Maximize(eta) */
+            maximize(eta, zero, n, budget, cfg, e_tmp, idx_tmp);
+        m = 1;
+        dist[0] = 1.0;
+        A[0 * ld + 0] = -(double)n; A[0 * ld + 1] = 1.0; A[1 * ld + 0] = 1.0; A[1 * ld + 1] = 0.0;
+
+        int changed = 1, st = SM_MAXITER, it;
+        double tau = 0.0;
+        for (it = 0; it < max_iter; ++it) {
+            int same = 1;
+            if (changed) {
+                bvec[0] = 1.0;
+                for (int i = 0; i < m; ++i) { /* Evaluate under eta = [x; 0] */
+                    double v = 0.0;
+                    for (int k = 0; k < n; ++k) v += bit_of(cfg + i * W, k) ? eta[k] : 0.0;
+                    bvec[i + 1] = v;
+                }
+                for (int c = 0; c <= m; ++c) {
+                    double acc = 0.0;
+                    for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
+                    if (c == 0) tau = acc; else z[c - 1] = acc;
+                }
+                same = 0;
+            }
+            if (same) {
+                for (int k = 0; k < n; ++k) { mu_on[k] = 0.0; mu_off[k] = 0.0; }
+                for (int i = 0; i < m; ++i)
+                    for (int k = 0; k < n; ++k)
+                        if (bit_of(cfg + i * W, k)) mu_on[k] += z[i]; else mu_off[k] += z[i];
+                for (int k = 0; k < n; ++k) { mu_on[k] = eta[k] - mu_on[k]; mu_off[k] = 0.0 - mu_off[k]; }
+                double value = maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
+                if (value <= tau + 1e-9) { st = SM_CONVERGED; break; }
+                int dup = 0;
+                for (int i = 0; i < m && !dup; ++i) dup = (memcmp(cfg + i * W, newc, sizeof(uint32_t) * W) == 0);
+                if (dup) { st = SM_DUPLICATE; break; }
+                if (m >= cap) { st = SM_SINGULAR; break; } /* n+1 affinely independent vertices at most */
+                z[m] = 0.0;
+                for (int i = 0; i <= m; ++i) dist[i] = z[i];
+                /* InvertAfterInsertion */
+                r[0] = 1.0;
+                for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
+                for (int j = 0; j <= m; ++j) {
+                    double acc = 0.0;
+                    for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; acc += A[i * ld + j] * r[i]; }
+                    d[j] = acc;
+                }
+                double s = (double)n;
+                for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
+                if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
+                double invs = 1.0 / s;
+                for (int i = 0; i <= m; ++i) {
+                    for (int j = 0; j <= m; ++j) A2[i * ld + j] = A[i * ld + j] + invs * d[i] * d[j];
+                    A2[i * ld + (m + 1)] = -invs * d[i];
+                    A2[(m + 1) * ld + i] = -invs * d[i];
+                }
+                A2[(m + 1) * ld + (m + 1)] = invs;
+                { double* t = A; A = A2; A2 = t; }
+                memcpy(cfg + m * W, newc, sizeof(uint32_t) * W);
+                ++m;
+                changed = 1;
+            } else {
+                int blocking = -1, exist = 0;
+                double alpha = 1.0;
+                for (int i = 0; i < m; ++i) {
+                    if (z[i] >= dist[i]) continue;
+                    if (z[i] < 0) exist = 1;
+                    double tmp = dist[i] / (dist[i] - z[i]);
+                    if (blocking < 0 || tmp < alpha) { alpha = tmp; blocking = i; }
+                }
+                if (!exist) {
+                    for (int i = 0; i < m; ++i) dist[i] = z[i];
+                    changed = 0;
+                } else {
+                    if (alpha > 1.0) alpha = 1.0;
+                    if (alpha == 1.0) {
+                        for (int i = 0; i < m; ++i) dist[i] = z[i];
+                    } else {
+                        for (int i = 0; i < m; ++i) {
+                            z[i] = (1 - alpha) * dist[i] + alpha * z[i];
+                            dist[i] = z[i];
+                        }
+                    }
+                    /* InvertAfterRemoval */
+                    int ri = blocking + 1;
+                    double invs = A[ri * ld + ri];
+                    double sdiv = 1.0 / invs;
+                    int kk = 0;
+                    for (int i = 0; i <= m; ++i) { if (i == ri) continue; d[kk++] = -sdiv * A[ri * ld + i]; }
+                    kk = 0;
+                    for (int i = 0; i <= m; ++i) {
+                        if (i == ri) continue;
+                        int l = 0;
+                        for (int j = 0; j <= m; ++j) {
+                            if (j == ri) continue;
+                            A2[kk * ld + l] = A[i * ld + j] - invs * d[kk] * d[l];
+                            ++l;
+                        }
+                        ++kk;
+                    }
+                    { double* t = A; A = A2; A2 = t; }
+                    for (int i = blocking; i < m - 1; ++i) {
+                        memcpy(cfg + i * W, cfg + (i + 1) * W, sizeof(uint32_t) * W);
+                        z[i] = z[i + 1];
+                        dist[i] = dist[i + 1];
+                    }
+                    --m;
+                    changed = 1;
+                }
+            }
+        }
+        /* outputs */
+        memset(aset_bits + s_ * cap * W, 0, sizeof(uint32_t) * (size_t)cap * W);
+        memcpy(aset_bits + s_ * cap * W, cfg, sizeof(uint32_t) * (size_t)m * W);
+        for (int i = 0; i < cap; ++i) {
+            p[s_ * cap + i] = (i < m) ? (float)dist[i] : 0.0f;
+            if (p64) p64[s_ * cap + i] = (i < m) ? dist[i] : 0.0;
+        }
+        alen[s_] = m;
+        if (invA_out) {
+            double* o = invA_out + s_ * (int64_t)ld * ld;
+            memset(o, 0, sizeof(double) * (size_t)ld * ld);
+            for (int i = 0; i <= m; ++i) for (int j = 0; j <= m; ++j) o[i * ld + j] = A[i * ld + j];
+        }
+        if (iters) iters[s_] = it;
+        if (status) status[s_] = st;
+    }
+    free(eta); free(zero); free(mu_on); free(mu_off); free(e_tmp); free(idx_tmp); free(A); free(A2);
+    free(z); free(dist); free(bvec); free(r); free(d); free(cfg); free(newc);
+    return 0;
+}
+
+/* dp[B,cap] fp32 (entries >= alen ignored) -> dscores[B,n] fp32.
+ * dist_jacobian_vec: tmp = S dp with S = invA[1:,1:], d_eta_u = M tmp, first n entries
+ * (sparsemap.py:38-44). */
+int oracle_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
+                         const double* invA, int64_t B, int32_t n, float* dscores)
+{
+    const int cap = n + 1, W = SM_WORDS(n), ld = cap + 1;
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)cap);
+    for (int64_t s_ = 0; s_ < B; ++s_) {
+        const int m = alen[s_];
+        const double* A = invA + s_ * (int64_t)ld * ld;
+        for (int i = 0; i < m; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < m; ++j) acc += A[(i + 1) * ld + (j + 1)] * (double)dp[s_ * cap + j];
+            tmp[i] = acc;
+        }
+        for (int k = 0; k < n; ++k) {
+            double acc = 0.0;
+            for (int i = 0; i < m; ++i)
+                if (bit_of(aset_bits + (s_ * cap + i) * W, k)) acc += tmp[i];
+            dscores[s_ * n + k] = (float)acc;
+        }
+    }
+    free(tmp);
+    return 0;
+}
