@@ -1,0 +1,137 @@
+/*
+ * sparsemarg.h -- C ABI of the MI355X-native sparse-marginalization hot path.
+ *
+ * Drop-in boundary for the hot path of deep-spin/sparse-marginalization-lvm (`lvmhelpers`):
+ * every entry point takes raw DEVICE pointers, sizes and a HIP stream (`void* stream` is a
+ * `hipStream_t`; NULL = the default stream), launches on that stream, never synchronises, never
+ * allocates (scratch comes in through explicit `workspace` arguments whose size the matching
+ * `*_workspace_bytes` function reports) and returns 0 or a negative SMLVM_ERR_* code.  No torch
+ * types appear here; the Python host side (`lvmhelpers/_native.py`) binds these with ctypes.
+ * Citations are file:line into the reference repository.
+ *
+ * Library: sparse-marginalization-lvm_amd/csrc/libsparsemarg_hip.so (gfx950 code object).
+ */
+#ifndef SPARSEMARG_H_
+#define SPARSEMARG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMLVM_ABI_VERSION 1
+
+#define SMLVM_OK 0
+#define SMLVM_ERR_INVALID (-1)     /* null pointer, negative size, bad combination of arguments */
+#define SMLVM_ERR_UNSUPPORTED (-2) /* size outside what the kernels are built for */
+#define SMLVM_ERR_HIP (-3)         /* the HIP runtime refused the launch (see smlvm_last_hip_error) */
+#define SMLVM_ERR_WORKSPACE (-4)   /* workspace missing or too small */
+
+/* Limits (smlvm_* returns SMLVM_ERR_UNSUPPORTED beyond them). */
+#define SMLVM_TOPK_MAX_BITS 512 /* lvmhelpers/binary_topk.h:13 CODE_MAX_SIZE */
+#define SMLVM_TOPK_MAX_K 64
+#define SMLVM_SPARSEMAP_MAX_BITS 128
+
+int smlvm_abi_version(void);
+const char* smlvm_error_string(int code);
+/* hipError_t (as int) of the last failed launch on the calling thread, 0 if none. */
+int smlvm_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel 1: batched row-wise sparsemax.
+ * Replaces entmax.sparsemax(X, dim=-1) as called at lvmhelpers/marg.py:45,51 and
+ * lvmhelpers/structmarg.py:48 (forward) and its autograd backward.
+ *   x, p, dy, dx : [R, K] fp32 row-major contiguous;  supp_size : [R] int32 (entmax's support_size,
+ *   the divisor of the backward);  optional outputs (NULL to skip): nnz [R] int32 = #{p > 0},
+ *   tau [R] fp32 (threshold in the max-shifted row), entropy [R] fp32 (lvmhelpers/marg.py:6-28).
+ * p = max(x - max(x) - tau, 0).  dx = [p != 0] * (dy - sum(dy[p != 0]) / supp_size).
+ * Inputs and outputs must not overlap.
+ */
+int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
+                        float* entropy, int64_t R, int32_t K, void* stream);
+int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_size, float* dx,
+                        int64_t R, int32_t K, void* stream);
+
+/* Shannon entropy with exact zeros, lvmhelpers/marg.py:6-28 (also structmarg.py:9-20):
+ * ent[r] = -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps), eps = FLT_EPSILON. */
+int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel 2: non-zero-support stream compaction + probability-weighted loss reduction.
+ * Replaces the boolean-mask compaction of lvmhelpers/structmarg.py:113-126 (mask = p.view(-1) > 0,
+ * row-major order identical to torch.nonzero) and the `p @ loss` contractions of
+ * lvmhelpers/marg.py:125, structmarg.py:140,242.
+ *   support_count   : nnz[r] = #{p[r,:] > 0}
+ *   support_offsets : row_offsets[0..R] = exclusive prefix sum of nnz (row_offsets[R] = N), int64
+ *   support_compact : for the j-th positive entry of row r (ascending column):
+ *                     rows[row_offsets[r]+j] = r, cols[..] = column, vals[..] = p[r, column]
+ *                     (any of rows/cols/vals may be NULL)
+ *   weighted_loss_reduce_fwd : row_out[r] = sum_{j in row r} vals[j]*comps[j] (nullable),
+ *                     total[0] = inv_b * sum_j vals[j]*comps[j]  (deterministic order, fp64 accumulate)
+ *   weighted_loss_reduce_bwd : dvals[j] = g*inv_b*comps[j], dcomps[j] = g*inv_b*vals[j], g = gtotal[0]
+ *                     (either output may be NULL)
+ */
+int smlvm_support_count(const float* p, int32_t* nnz, int64_t R, int32_t K, void* stream);
+size_t smlvm_support_offsets_workspace_bytes(int64_t R);
+int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, int64_t R, void* workspace,
+                          size_t workspace_bytes, void* stream);
+int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows, int32_t* cols,
+                          float* vals, int64_t R, int32_t K, void* stream);
+size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N);
+int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps, const int64_t* row_offsets,
+                                   float* row_out, float* total, float inv_b, int64_t R, int64_t N,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int smlvm_weighted_loss_reduce_bwd(const float* vals, const float* comps, const float* gtotal,
+                                   float inv_b, float* dvals, float* dcomps, int64_t N,
+                                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * k-best bit vectors. Replaces lvmhelpers/pbinary_topk.pyx:23-34 batched_topk (which calls
+ * lvmhelpers/binary_topk.h:100-135 per row on the host).
+ *   scores [B, n] fp32 -> configs [B, k, n] fp32 in {0,1}, sorted by descending score
+ *   (ties: the reference's merge order, binary_topk.h:72); topscores [B, k] fp32 (nullable) are
+ *   the fp32 sums accumulated in index order (binary_topk.h:28).
+ * Requires 2 <= k <= min(2^n, SMLVM_TOPK_MAX_K), 1 <= n <= SMLVM_TOPK_MAX_BITS (the reference has
+ * undefined behaviour outside 2 <= k <= 2^n; this returns SMLVM_ERR_INVALID instead).
+ */
+int smlvm_binary_topk_batched(const float* scores, float* configs, float* topscores, int64_t B,
+                              int32_t n, int32_t k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Kernel 3: bit-vector SparseMAP, one wavefront per sample.
+ * Replaces, for a whole batch at once, lvmhelpers/sparsemap.py:12-36 (run_sparsemap: factor graph
+ * construction, optional init_active_set_from_scores, lpsmap GenericFactor::SolveQP,
+ * get_sparse_solution) with the FactorBernoulli / FactorBudget oracles of
+ * lvmhelpers/bernoulli.h:14-109 and lvmhelpers/budget.h:24-85, and lvmhelpers/sparsemap.py:38-44
+ * (jv -> dist_jacobian_vec) for the backward.
+ *   scores      [B, n] fp32            (eta = [scores.double(); 0], sparsemap.py:21-22)
+ *   init_scores [B, 2n] fp64 or NULL   (torch.rand(2n, dtype=double) per sample, sparsemap.py:25-27)
+ *   budget      0 = Bernoulli factor, >0 = budget factor;  max_iter as in solve_qp(max_iter=)
+ * With cap = n+1, W = ceil(n/32), ld = n+2:
+ *   aset_bits [B, cap, W] uint32   active configurations (bit k%32 of word k/32 = variable k on)
+ *   p         [B, cap] fp32        distribution over the active set, zero beyond alen[b]
+ *   alen      [B] int32            len(aset)
+ *   inv_a     [B, ld, ld] fp64     cached inverse KKT matrix (rows/cols 0..alen[b] written); the
+ *                                  state the reference keeps on ctx.f between forward and backward
+ *   iters     [B] int32, status [B] int32 (0 converged, 1 max_iter, 2 singular, 3 duplicate); nullable
+ * Backward: dp [B, cap] fp32 -> dscores [B, n] fp32.
+ */
+int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
+                        int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                        int32_t* alen, double* inv_a, int32_t* iters, int32_t* status,
+                        void* stream);
+int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
+                        const double* inv_a, int64_t B, int32_t n, float* dscores, void* stream);
+
+/* Expand compacted (sample, slot) pairs into 0/1 float rows: out[j, :] = bits of
+ * aset_bits[rows[j], cols[j], :]  (the `samplei[distri > 0]` gather + torch.cat of
+ * lvmhelpers/structmarg.py:189,198).  out [N, n] fp32. */
+int smlvm_unpack_configs(const uint32_t* aset_bits, const int32_t* rows, const int32_t* cols,
+                         float* out, int64_t N, int32_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEMARG_H_ */

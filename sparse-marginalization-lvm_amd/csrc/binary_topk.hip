@@ -1,0 +1,126 @@
+// k-best assignments of n independent binary variables, batched on the GPU.
+//
+// Replaces lvmhelpers/pbinary_topk.pyx:23-34 (batched_topk) and the per-row host DP of
+// lvmhelpers/binary_topk.h:57-129.  One group of G lanes (16 or 64) per sample, list slot j on lane
+// j.  Each DP step merges the sorted list `a` (bit i off) with `b = a + x_i` (bit i on) by merge
+// ranks instead of a serial two-pointer walk:
+//     rank(a_j) = j + #{l : b_l >  a_j}      (b is taken only if STRICTLY greater, binary_topk.h:72)
+//     rank(b_l) = l + #{j : a_j >= b_l}
+// which reproduces the reference's merge order exactly, ties included; ranks >= k are dropped.
+// Scores are fp32 sums accumulated in index order (binary_topk.h:28), so they match bit for bit.
+#include "common.hpp"
+
+#include <math.h>
+
+namespace smlvm {
+
+template <int G, int W>
+__global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restrict__ scores,
+                                                          float* __restrict__ configs,
+                                                          float* __restrict__ topscores, int64_t B,
+                                                          int n, int k)
+{
+    constexpr int GPB = 256 / G;  // groups (samples) per block
+    __shared__ float s_score[256];
+    __shared__ int s_src[256];
+    __shared__ uint32_t s_cfg[256 * W];
+
+    const int lane = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int64_t sample = (int64_t)blockIdx.x * GPB + grp;
+    const bool live = sample < B;
+    const float* x = scores + (live ? sample : B - 1) * n;
+    float* gs = s_score + grp * G;
+    int* gi = s_src + grp * G;
+
+    uint32_t cfg[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) cfg[w] = 0u;
+    const float x0 = x[0];
+    const float c1 = 0.0f + x0;  // c0.update(0, x[0]), binary_topk.h:104-107
+    const bool on_first = x0 >= 0.0f;  // binary_topk.h:110-116
+    float a = -INFINITY;
+    if (lane == 0) { a = on_first ? c1 : 0.0f; cfg[0] = on_first ? 1u : 0u; }
+    if (lane == 1) { a = on_first ? 0.0f : c1; cfg[0] = on_first ? 0u : 1u; }
+    int L = 2;
+
+    for (int i = 1; i < n; ++i) {
+        const float xi = x[i];
+        const float b = a + xi;
+        int cntA = 0, cntB = 0;
+        for (int t = 0; t < L; ++t) {
+            const float at = __shfl(a, t, G);
+            const float bt = at + xi;
+            cntA += (bt > a) ? 1 : 0;
+            cntB += (at >= b) ? 1 : 0;
+        }
+        const int rA = lane + cntA, rB = lane + cntB;
+        if (lane < L && rA < k) { gs[rA] = a; gi[rA] = lane; }
+        if (lane < L && rB < k) { gs[rB] = b; gi[rB] = lane | 0x100; }
+        __syncthreads();
+        const int Ln = (2 * L < k) ? 2 * L : k;
+        float na = -INFINITY;
+        int src = lane;
+        if (lane < Ln) { na = gs[lane]; src = gi[lane]; }
+        __syncthreads();
+        const int sl = src & 0xff;
+        const uint32_t bit = (src & 0x100) ? (1u << (i & 31)) : 0u;
+        const int wi = i >> 5;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            uint32_t v = (uint32_t)__shfl((int)cfg[w], sl, G);
+            cfg[w] = v | ((w == wi) ? bit : 0u);
+        }
+        a = na;
+        L = Ln;
+    }
+
+    // cooperative, coalesced write of the [k, n] block of 0/1 floats
+    uint32_t* gc = s_cfg + grp * G * W;
+#pragma unroll
+    for (int w = 0; w < W; ++w) gc[lane * W + w] = cfg[w];
+    __syncthreads();
+    if (live) {
+        float* out = configs + sample * (int64_t)k * n;
+        const int total = k * n;
+        for (int idx = lane; idx < total; idx += G) {
+            const int j = idx / n, i = idx - j * n;
+            out[idx] = (float)((gc[j * W + (i >> 5)] >> (i & 31)) & 1u);
+        }
+        if (topscores && lane < k) topscores[sample * k + lane] = a;
+    }
+}
+
+template <int G>
+static void launch_topk(const float* scores, float* configs, float* topscores, int64_t B, int n,
+                        int k, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((B + (256 / G) - 1) / (256 / G));
+    const int W = (n + 31) / 32;
+#define SMLVM_TOPK_GO(WW)                                                                         \
+    hipLaunchKernelGGL((binary_topk_kernel<G, WW>), dim3(grid), dim3(256), 0, st, scores, configs, \
+                       topscores, B, n, k)
+    if (W <= 1) SMLVM_TOPK_GO(1);
+    else if (W <= 2) SMLVM_TOPK_GO(2);
+    else if (W <= 4) SMLVM_TOPK_GO(4);
+    else if (W <= 8) SMLVM_TOPK_GO(8);
+    else SMLVM_TOPK_GO(16);
+#undef SMLVM_TOPK_GO
+}
+
+}  // namespace smlvm
+
+using namespace smlvm;
+
+extern "C" int smlvm_binary_topk_batched(const float* scores, float* configs, float* topscores,
+                                         int64_t B, int32_t n, int32_t k, void* stream)
+{
+    if (B < 0 || n < 1 || k < 2) return SMLVM_ERR_INVALID;
+    if (n < 31 && (int64_t)k > ((int64_t)1 << n)) return SMLVM_ERR_INVALID;
+    if (n > SMLVM_TOPK_MAX_BITS || k > SMLVM_TOPK_MAX_K) return SMLVM_ERR_UNSUPPORTED;
+    if (B == 0) return SMLVM_OK;
+    if (!scores || !configs) return SMLVM_ERR_INVALID;
+    if (k <= 16) launch_topk<16>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
+    else launch_topk<64>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
+    return check_launch();
+}

@@ -1,0 +1,376 @@
+// Kernel 2: non-zero-support stream compaction and the probability-weighted loss reduction.
+//
+// Replaces the boolean-mask compaction of lvmhelpers/structmarg.py:113-126 (row-major order of
+// torch.nonzero(p > 0)) and the p @ loss contractions of lvmhelpers/marg.py:125,
+// lvmhelpers/structmarg.py:140,242.
+//
+// All kernels are HBM streaming work: one wave per row, 16-byte loads per lane, ballot + mbcnt for
+// the in-row ordered positions; 128-byte groups with no positive entry are skipped wave-uniformly.
+#include "common.hpp"
+
+namespace smlvm {
+
+constexpr int kScanItemsPerBlock = 2048;  // 256 threads x 8 items
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// ------------------------------------------------------------------------------- count
+template <bool VEC>
+__global__ __launch_bounds__(256) void support_count_kernel(const float* __restrict__ p,
+                                                            int32_t* __restrict__ nnz, int64_t R,
+                                                            int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* pr = p + row * K;
+    int c = 0;
+    if constexpr (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const int K4 = K >> 2;
+        for (int f = lane; f < K4; f += 64) {
+            float4 v = p4[f];
+            c += (v.x > 0.0f) + (v.y > 0.0f) + (v.z > 0.0f) + (v.w > 0.0f);
+        }
+    } else {
+        for (int j = lane; j < K; j += 64) c += pr[j] > 0.0f;
+    }
+    c = group_reduce<64>(c, OpSum{});
+    if (lane == 0) nnz[row] = c;
+}
+
+// ------------------------------------------------------------------------------- offsets
+// Three-phase exclusive scan of nnz[R] -> row_offsets[R+1] (int64), block sums in the workspace.
+__device__ __forceinline__ long long block_exclusive_scan(long long v, long long* lds,
+                                                          long long& total)
+{
+    // inclusive scan inside the wave with shuffles, then across the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        long long s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void scan_block_sums_kernel(const int32_t* __restrict__ nnz,
+                                                              long long* __restrict__ block_sums,
+                                                              int64_t R)
+{
+    const int64_t base = (int64_t)blockIdx.x * kScanItemsPerBlock;
+    long long s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItemsPerBlock / 256; ++i) {
+        int64_t idx = base + i * 256 + threadIdx.x;
+        if (idx < R) s += nnz[idx];
+    }
+    s = group_reduce<64>((double)s, OpSum{});  // exact: < 2^53
+    __shared__ long long lds[4];
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ __launch_bounds__(256) void scan_of_sums_kernel(long long* __restrict__ block_sums,
+                                                           int64_t nblocks)
+{
+    __shared__ long long lds[4];
+    long long carry = 0;
+    for (int64_t start = 0; start < nblocks; start += 256) {
+        int64_t idx = start + threadIdx.x;
+        long long v = idx < nblocks ? block_sums[idx] : 0;
+        long long total;
+        long long ex = block_exclusive_scan(v, lds, total);
+        if (idx < nblocks) block_sums[idx] = carry + ex;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restrict__ nnz,
+                                                         const long long* __restrict__ block_sums,
+                                                         int64_t* __restrict__ row_offsets,
+                                                         int64_t R)
+{
+    __shared__ long long lds[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanItemsPerBlock;
+    // thread t owns 8 consecutive items so the per-thread serial part stays in order
+    const int64_t first = base + (int64_t)threadIdx.x * 8;
+    long long v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        v[i] = (first + i < R) ? nnz[first + i] : 0;
+        s += v[i];
+    }
+    long long total;
+    long long ex = block_exclusive_scan(s, lds, total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (first + i < R) row_offsets[first + i] = ex;
+        ex += v[i];
+        if (first + i == R - 1) row_offsets[R] = ex;
+    }
+}
+
+// ------------------------------------------------------------------------------- compact
+template <bool VEC>
+__global__ __launch_bounds__(256) void support_compact_kernel(
+    const float* __restrict__ p, const int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows,
+    int32_t* __restrict__ cols, float* __restrict__ vals, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* pr = p + row * K;
+    int64_t out = row_offsets[row];
+    if constexpr (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const int K4 = K >> 2;
+        for (int f0 = 0; f0 < K4; f0 += 64) {
+            const int f = f0 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < K4) v = p4[f];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            const int mine = (e[0] > 0.0f) + (e[1] > 0.0f) + (e[2] > 0.0f) + (e[3] > 0.0f);
+            if (__ballot(mine != 0) == 0ull) continue;  // wave-uniform: nothing in these 1 KiB
+            // exclusive prefix of `mine` over lanes: column order is (lane, component)
+            int pre = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                int o = __shfl_up(pre, d);
+                if (lane >= d) pre += o;
+            }
+            const int total = __shfl(pre, 63);
+            int64_t pos = out + (pre - mine);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (e[c] > 0.0f) {
+                    if (rows) rows[pos] = (int32_t)row;
+                    if (cols) cols[pos] = f * 4 + c;
+                    if (vals) vals[pos] = e[c];
+                    ++pos;
+                }
+            }
+            out += total;
+        }
+    } else {
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = j < K ? pr[j] : 0.0f;
+            const unsigned long long m = __ballot(v > 0.0f);
+            if (m == 0ull) continue;
+            if (v > 0.0f) {
+                const int64_t pos = out + lanes_below(m);
+                if (rows) rows[pos] = (int32_t)row;
+                if (cols) cols[pos] = j;
+                if (vals) vals[pos] = v;
+            }
+            out += __popcll(m);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- weighted reduce
+// Fixed-shape, order-deterministic two-stage sum: stage 1 gives each of up to kRedBlocks blocks a
+// contiguous slice of the N products (fp64), stage 2 folds the partials in index order.
+constexpr int kRedBlocks = 1024;
+
+__global__ __launch_bounds__(256) void wlr_rows_kernel(const float* __restrict__ vals,
+                                                       const float* __restrict__ comps,
+                                                       const int64_t* __restrict__ row_offsets,
+                                                       float* __restrict__ row_out, int64_t R)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    double acc = 0.0;
+    for (int64_t j = row_offsets[r]; j < row_offsets[r + 1]; ++j)
+        acc += (double)vals[j] * (double)comps[j];
+    row_out[r] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void wlr_partial_kernel(const float* __restrict__ vals,
+                                                          const float* __restrict__ comps,
+                                                          double* __restrict__ partials, int64_t N,
+                                                          int64_t per_block)
+{
+    __shared__ double lds[4];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = lo + per_block < N ? lo + per_block : N;
+    double acc = 0.0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) acc += (double)vals[j] * (double)comps[j];
+    acc = group_reduce<64>(acc, OpSum{});
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+__global__ __launch_bounds__(64) void wlr_final_kernel(const double* __restrict__ partials,
+                                                       int nparts, float inv_b,
+                                                       float* __restrict__ total)
+{
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < nparts; j += 64) acc += partials[j];
+    acc = group_reduce<64>(acc, OpSum{});
+    if (threadIdx.x == 0) total[0] = (float)(acc * (double)inv_b);
+}
+
+__global__ __launch_bounds__(256) void wlr_bwd_kernel(const float* __restrict__ vals,
+                                                      const float* __restrict__ comps,
+                                                      const float* __restrict__ gtotal, float inv_b,
+                                                      float* __restrict__ dvals,
+                                                      float* __restrict__ dcomps, int64_t N)
+{
+    const float g = gtotal[0] * inv_b;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256) {
+        if (dvals) dvals[j] = g * comps[j];
+        if (dcomps) dcomps[j] = g * vals[j];
+    }
+}
+
+// ------------------------------------------------------------------------------- unpack
+__global__ __launch_bounds__(256) void unpack_configs_kernel(const uint32_t* __restrict__ aset_bits,
+                                                             const int32_t* __restrict__ rows,
+                                                             const int32_t* __restrict__ cols,
+                                                             float* __restrict__ out, int64_t N,
+                                                             int n, int cap, int W)
+{
+    const int64_t total = N * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int64_t j = i / n;
+        const int k = (int)(i - j * n);
+        const uint32_t w = aset_bits[((int64_t)rows[j] * cap + cols[j]) * W + (k >> 5)];
+        out[i] = (float)((w >> (k & 31)) & 1u);
+    }
+}
+
+}  // namespace smlvm
+
+using namespace smlvm;
+
+extern "C" int smlvm_support_count(const float* p, int32_t* nnz, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!p || !nnz) return SMLVM_ERR_INVALID;
+    const unsigned grid = (unsigned)((R + 3) / 4);
+    if (K % 4 == 0 && aligned16(p))
+        hipLaunchKernelGGL(support_count_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, nnz, R, K);
+    else
+        hipLaunchKernelGGL(support_count_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, nnz, R, K);
+    return check_launch();
+}
+
+extern "C" size_t smlvm_support_offsets_workspace_bytes(int64_t R)
+{
+    if (R <= 0) return 8;
+    return (size_t)((R + kScanItemsPerBlock - 1) / kScanItemsPerBlock) * sizeof(long long);
+}
+
+extern "C" int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, int64_t R,
+                                     void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (R < 0 || !row_offsets) return SMLVM_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        return SMLVM_OK;
+    }
+    if (!nnz) return SMLVM_ERR_INVALID;
+    if (!workspace || workspace_bytes < smlvm_support_offsets_workspace_bytes(R))
+        return SMLVM_ERR_WORKSPACE;
+    const int64_t nblocks = (R + kScanItemsPerBlock - 1) / kScanItemsPerBlock;
+    long long* sums = (long long*)workspace;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, R);
+    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(256), 0, st, sums, nblocks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, row_offsets, R);
+    return check_launch();
+}
+
+extern "C" int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows,
+                                     int32_t* cols, float* vals, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!p || !row_offsets) return SMLVM_ERR_INVALID;
+    const unsigned grid = (unsigned)((R + 3) / 4);
+    if (K % 4 == 0 && aligned16(p))
+        hipLaunchKernelGGL(support_compact_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, row_offsets, rows, cols, vals, R, K);
+    else
+        hipLaunchKernelGGL(support_compact_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, row_offsets, rows, cols, vals, R, K);
+    return check_launch();
+}
+
+extern "C" size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N)
+{
+    (void)N;
+    return (size_t)kRedBlocks * sizeof(double);
+}
+
+extern "C" int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps,
+                                              const int64_t* row_offsets, float* row_out,
+                                              float* total, float inv_b, int64_t R, int64_t N,
+                                              void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (R < 0 || N < 0) return SMLVM_ERR_INVALID;
+    if (N > 0 && (!vals || !comps)) return SMLVM_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (row_out && R > 0) {
+        if (!row_offsets) return SMLVM_ERR_INVALID;
+        hipLaunchKernelGGL(wlr_rows_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, vals, comps, row_offsets, row_out, R);
+    }
+    if (total) {
+        if (!workspace || workspace_bytes < smlvm_weighted_loss_reduce_workspace_bytes(N))
+            return SMLVM_ERR_WORKSPACE;
+        double* partials = (double*)workspace;
+        int64_t per_block = (N + kRedBlocks - 1) / kRedBlocks;
+        if (per_block < 256) per_block = 256;
+        int nparts = (int)((N + per_block - 1) / per_block);
+        if (nparts > 0)
+            hipLaunchKernelGGL(wlr_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, comps, partials, N, per_block);
+        hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, inv_b, total);
+    }
+    return check_launch();
+}
+
+extern "C" int smlvm_weighted_loss_reduce_bwd(const float* vals, const float* comps,
+                                              const float* gtotal, float inv_b, float* dvals,
+                                              float* dcomps, int64_t N, void* stream)
+{
+    if (N < 0) return SMLVM_ERR_INVALID;
+    if (N == 0) return SMLVM_OK;
+    if (!vals || !comps || !gtotal) return SMLVM_ERR_INVALID;
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wlr_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vals, comps, gtotal, inv_b, dvals, dcomps, N);
+    return check_launch();
+}
+
+extern "C" int smlvm_unpack_configs(const uint32_t* aset_bits, const int32_t* rows,
+                                    const int32_t* cols, float* out, int64_t N, int32_t n,
+                                    void* stream)
+{
+    if (N < 0 || n < 1) return SMLVM_ERR_INVALID;
+    if (N == 0) return SMLVM_OK;
+    if (!aset_bits || !rows || !cols || !out) return SMLVM_ERR_INVALID;
+    int64_t blocks = (N * n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(unpack_configs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, aset_bits, rows, cols, out, N, n, n + 1, (n + 31) / 32);
+    return check_launch();
+}

@@ -1,0 +1,635 @@
+// Kernel 1: batched row-wise sparsemax forward / backward for gfx950 (wave64).
+//
+// Replaces entmax.sparsemax as called at lvmhelpers/marg.py:45,51 and lvmhelpers/structmarg.py:48.
+//
+// Design (HBM-bound: 8K B/row forward, 12K B/row backward, one read and one write per element):
+//   * a row lives entirely in registers: G lanes x E elements (G = 8..64 lanes of one wave for
+//     K <= 4096, several rows packed per wave when K is small; a whole workgroup of NW waves for
+//     4096 < K <= 65536), loaded with one coalesced 16-byte load per lane per 4 elements;
+//   * the threshold tau is found without sorting: Michelot's fixed point iteration (a Newton
+//     iteration from the left on the piecewise-linear equation sum(max(z - tau, 0)) = 1) started
+//     from the bound tau >= max - 1, each step one pass over the registers plus a DPP all-reduce
+//     inside the lane group;
+//   * the result is then made bit-identical to the sort-based definition (oracle/sparsemax_oracle.c:
+//     fp64-accumulated prefix sums rounded to fp32, fp32 test j*z_(j) > c_j): the boundary ranks
+//     are re-tested with exactly those fp32 expressions, from an fp64 sum of the candidate set,
+//     and the set is moved rank by rank until the test flips exactly at its edge;
+//   * epilogue fused: p = max(z - tau, 0), support size, #{p>0}, optional entropy.
+// Backward: dx = [p != 0] * (dy - sum(dy[p != 0]) / supp_size), fp64 row sum.
+#include "common.hpp"
+
+#include <float.h>
+#include <math.h>
+
+namespace smlvm {
+
+// ------------------------------------------------------------------------------- reducers
+// A reducer combines per-lane partials over everything that holds one row.  `cs` and `edge`
+// reduce several values in ONE step: for the workgroup reducer that is one barrier, and it keeps
+// the per-element compare masks from having to stay alive (in SGPRs) from one pass to the next.
+template <int G>
+struct WaveRed {
+    __device__ __forceinline__ float max(float v) { return group_reduce<G>(v, OpMaxF{}); }
+    __device__ __forceinline__ float min(float v) { return group_reduce<G>(v, OpMinF{}); }
+    __device__ __forceinline__ int sum(int v) { return group_reduce<G>(v, OpSum{}); }
+    __device__ __forceinline__ double sum(double v) { return group_reduce<G>(v, OpSum{}); }
+    __device__ __forceinline__ void cs(int& c, float& s)
+    {
+        c = group_reduce<G>(c, OpSum{});
+        s = group_reduce<G>(s, OpSum{});
+    }
+    __device__ __forceinline__ void edge(int& mg, int& t, double& S, float& vn)
+    {
+        mg = group_reduce<G>(mg, OpSum{});
+        t = group_reduce<G>(t, OpSum{});
+        S = group_reduce<G>(S, OpSum{});
+        vn = group_reduce<G>(vn, OpMaxF{});
+    }
+};
+
+// Whole-workgroup all-reduce through LDS, one barrier per call: each wave reduces with DPP, lane 0
+// parks the wave totals in an LDS record, and after the barrier every wave re-reduces the NW
+// records (one per lane, identity elsewhere) with the same DPP tree, so all threads get the same
+// bits.  Three rotating record sets: a wave can be at most one reduction ahead of the slowest one,
+// whose reads of the previous set are done before it reaches the barrier that lets anyone write
+// the set after next.
+template <int NW>
+struct BlockRed {
+    static_assert(NW <= 16, "second level is one 16-lane DPP row");
+    static constexpr int kSlots = 3;            // 8-byte slots per wave record
+    static constexpr int kLdsWords = 3 * NW * kSlots;  // unsigned long long words
+    unsigned long long* base;
+    int phase;
+    __device__ __forceinline__ BlockRed(unsigned long long* lds) : base(lds), phase(0) {}
+    __device__ __forceinline__ unsigned long long* next_set()
+    {
+        unsigned long long* s = base + phase * NW * kSlots;
+        phase = (phase == 2) ? 0 : phase + 1;
+        return s;
+    }
+    template <class T>
+    static __device__ __forceinline__ unsigned long long pack(T v)
+    {
+        unsigned long long bits = 0;
+        __builtin_memcpy(&bits, &v, sizeof(T));
+        return bits;
+    }
+    template <class T>
+    static __device__ __forceinline__ T unpack(unsigned long long bits)
+    {
+        T v;
+        __builtin_memcpy(&v, &bits, sizeof(T));
+        return v;
+    }
+    template <class T>
+    static __device__ __forceinline__ T bcast0(T v)
+    {
+        if constexpr (sizeof(T) == 8)
+            return __builtin_bit_cast(T, readlane_f64(__builtin_bit_cast(double, v), 0));
+        else
+            return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    }
+    template <class T, class Op>
+    __device__ __forceinline__ T all(T v, Op op, T identity)
+    {
+        v = group_reduce<64>(v, op);
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) s[(threadIdx.x >> 6) * kSlots] = pack(v);
+        __syncthreads();
+        T part = identity;
+        if (lane < NW) part = unpack<T>(s[lane * kSlots]);
+        return bcast0(group_reduce<16>(part, op));
+    }
+    __device__ __forceinline__ float max(float v) { return all(v, OpMaxF{}, -INFINITY); }
+    __device__ __forceinline__ float min(float v) { return all(v, OpMinF{}, INFINITY); }
+    __device__ __forceinline__ int sum(int v) { return all(v, OpSum{}, 0); }
+    __device__ __forceinline__ double sum(double v) { return all(v, OpSum{}, 0.0); }
+    __device__ __forceinline__ void cs(int& c, float& sm)
+    {
+        c = group_reduce<64>(c, OpSum{});
+        sm = group_reduce<64>(sm, OpSum{});
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) {
+            unsigned long long* rec = s + (threadIdx.x >> 6) * kSlots;
+            rec[0] = pack(c);
+            rec[1] = pack(sm);
+        }
+        __syncthreads();
+        int pc = 0;
+        float ps = 0.0f;
+        if (lane < NW) {
+            pc = unpack<int>(s[lane * kSlots]);
+            ps = unpack<float>(s[lane * kSlots + 1]);
+        }
+        c = bcast0(group_reduce<16>(pc, OpSum{}));
+        sm = bcast0(group_reduce<16>(ps, OpSum{}));
+    }
+    __device__ __forceinline__ void edge(int& mg, int& t, double& S, float& vn)
+    {
+        mg = group_reduce<64>(mg, OpSum{});
+        t = group_reduce<64>(t, OpSum{});
+        S = group_reduce<64>(S, OpSum{});
+        vn = group_reduce<64>(vn, OpMaxF{});
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) {
+            unsigned long long* rec = s + (threadIdx.x >> 6) * kSlots;
+            rec[0] = ((unsigned long long)(unsigned)t << 32) | (unsigned)mg;
+            rec[1] = pack(S);
+            rec[2] = pack(vn);
+        }
+        __syncthreads();
+        int pm = 0, pt = 0;
+        double pS = 0.0;
+        float pv = -INFINITY;
+        if (lane < NW) {
+            unsigned long long w = s[lane * kSlots];
+            pm = (int)(unsigned)(w & 0xffffffffull);
+            pt = (int)(unsigned)(w >> 32);
+            pS = unpack<double>(s[lane * kSlots + 1]);
+            pv = unpack<float>(s[lane * kSlots + 2]);
+        }
+        mg = bcast0(group_reduce<16>(pm, OpSum{}));
+        t = bcast0(group_reduce<16>(pt, OpSum{}));
+        S = bcast0(group_reduce<16>(pS, OpSum{}));
+        vn = bcast0(group_reduce<16>(pv, OpMaxF{}));
+    }
+};
+
+// ------------------------------------------------------------------------------- exact edge
+// The oracle's test at rank j = m_gt + r inside the tie group of value v (r = 1..t), given the
+// count m_gt and fp64 sum S_gt of the elements strictly above v:
+//     (float)j * v  >  (float)(S_gt + r*v) - 1.0f
+__device__ __forceinline__ bool cond_rank(int m_gt, double S_gt, float v, int r)
+{
+    float j = (float)(m_gt + r);
+    double S = S_gt + (double)r * (double)v;  // r*v is exact in fp64
+    float c = (float)S - 1.0f;
+    return j * v > c;
+}
+
+struct Edge {
+    int m_gt, t;
+    double S_gt;
+    float vnext;
+};
+
+template <int E, class Red>
+__device__ __forceinline__ Edge edge_pass(const float (&z)[E], float lo, Red& red)
+{
+    int mg = 0, t = 0;
+    double S = 0.0;
+    float vn = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float v = z[e];
+        // opaque copy: stops LICM from hoisting 64 float->double conversions (128 VGPRs) out of
+        // the caller's edge loop
+        asm volatile("" : "+v"(v));
+        bool gt = v > lo;
+        mg += gt ? 1 : 0;
+        t += (v == lo) ? 1 : 0;
+        S += gt ? (double)v : 0.0;
+        vn = (v < lo) ? fmaxf(vn, v) : vn;
+    }
+    red.edge(mg, t, S, vn);
+    Edge r;
+    r.m_gt = mg;
+    r.t = t;
+    r.S_gt = S;
+    r.vnext = vn;
+    return r;
+}
+
+// z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
+template <int E, class Red>
+__device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, int& supp, float& tau_out)
+{
+    float mx = z[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    mx = red.max(mx);
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] -= mx;
+
+    // --- Michelot iteration from the lower bound tau >= -1 (z_max = 0 after the shift).
+    float tau = -1.0f;
+    int cnt_prev = 0x7fffffff;
+    for (;;) {
+        int c = 0;
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            bool in = z[e] > tau;
+            c += in ? 1 : 0;
+            s += in ? z[e] : 0.0f;
+        }
+        red.cs(c, s);
+        if (c >= cnt_prev) break;  // the set stopped shrinking: fixed point (up to fp32 rounding)
+        cnt_prev = c;
+        tau = fmaxf(tau, (s - 1.0f) / (float)c);
+    }
+
+    // --- exact edge: candidate set {z > tau} = {z >= lo}, lo = its smallest value.
+    // (tau is laundered so the compiler recomputes these compares instead of keeping the last
+    // iteration's 64 lane masks alive in SGPRs across the reductions)
+    asm volatile("" : "+v"(tau));
+    float lo = INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) lo = (z[e] > tau) ? fminf(lo, z[e]) : lo;
+    lo = red.min(lo);
+
+    int s_final;
+    double S_final;
+    int dir = 0;
+    for (;;) {
+        Edge b = edge_pass(z, lo, red);
+        int rstar;
+        if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
+            rstar = b.t;
+        } else if (b.t == 1 || !cond_rank(b.m_gt, b.S_gt, lo, 1)) {
+            rstar = 0;
+        } else {  // edge inside a tie group (rounding only): largest r whose test holds
+            int a = 1, hi = b.t;
+            while (hi - a > 1) {
+                int mid = (a + hi) >> 1;
+                if (cond_rank(b.m_gt, b.S_gt, lo, mid)) a = mid; else hi = mid;
+            }
+            rstar = a;
+        }
+        if (rstar == b.t) {
+            int m = b.m_gt + b.t;
+            double S_m = b.S_gt + (double)b.t * (double)lo;
+            if (dir >= 0 && b.vnext > -INFINITY && cond_rank(m, S_m, b.vnext, 1)) {
+                dir = 1;  // the next group still passes the test: grow
+                lo = b.vnext;
+                continue;
+            }
+            s_final = m;
+            S_final = S_m;
+            break;
+        }
+        if (rstar > 0 || dir > 0 || b.m_gt == 0) {
+            s_final = b.m_gt + rstar;
+            S_final = b.S_gt + (double)rstar * (double)lo;
+            if (s_final == 0) { s_final = b.t; S_final = (double)b.t * (double)lo; }  // unreachable for finite rows
+            break;
+        }
+        // the whole group fails: shrink to the next larger value
+        dir = -1;
+        float up = INFINITY;
+#pragma unroll
+        for (int e = 0; e < E; ++e) up = (z[e] > lo) ? fminf(up, z[e]) : up;
+        lo = red.min(up);
+    }
+
+    float c_s = (float)S_final - 1.0f;
+    float tau_f = c_s / (float)s_final;
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = fmaxf(z[e] - tau_f, 0.0f);
+    supp = s_final;
+    tau_out = tau_f;
+}
+
+template <int E, class Red>
+__device__ __forceinline__ void row_epilogue(const float (&p)[E], Red& red, bool want_nnz,
+                                             bool want_ent, int& nnz, float& ent)
+{
+    if (want_nnz) {
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) c += (p[e] > 0.0f) ? 1 : 0;
+        nnz = red.sum(c);
+    }
+    if (want_ent) {  // lvmhelpers/marg.py:18-28
+        double acc = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (p[e] > 0.0f) {
+                float pc = fminf(fmaxf(p[e], FLT_EPSILON), 1.0f - FLT_EPSILON);
+                acc += (double)(pc * logf(pc));
+            }
+        }
+        ent = -(float)red.sum(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------- row <-> regs
+// Lane `gl` of a group of GT lanes owns, for chunk i, the float4 with index i*GT + gl (VEC) or
+// the element i*GT + gl (scalar): every load/store instruction covers consecutive addresses.
+// FULL: K equals the tile capacity GT*E, so no bounds predicates are needed.
+template <int E, bool VEC, bool FULL>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int K, int gl, int GT,
+                                         float (&z)[E], float pad)
+{
+    if constexpr (VEC) {
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        const int K4 = K >> 2;
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) {
+            int f = i * GT + gl;
+            float4 v = make_float4(pad, pad, pad, pad);
+            if (FULL || f < K4) v = r4[f];
+            z[4 * i + 0] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int c = e * GT + gl;
+            z[e] = (c < K) ? row[c] : pad;
+        }
+    }
+}
+
+template <int E, bool VEC, bool FULL>
+__device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl, int GT,
+                                          const float (&z)[E])
+{
+    if constexpr (VEC) {
+        float4* r4 = reinterpret_cast<float4*>(row);
+        const int K4 = K >> 2;
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) {
+            int f = i * GT + gl;
+            if (FULL || f < K4) r4[f] = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            int c = e * GT + gl;
+            if (c < K) row[c] = z[e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- kernels
+constexpr int kWavesPerBlock = 4;
+// waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
+constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
+constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 4; }
+
+// EXTRA: any of the optional outputs (nnz, tau, entropy) requested.
+template <int G, int E, bool VEC, bool FULL, bool EXTRA>
+__global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void sparsemax_fwd_wave_kernel(
+    const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
+    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent, int64_t R, int K)
+{
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % G;
+    int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < R;
+    if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
+    float z[E];
+    load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
+    WaveRed<G> red;
+    int s, n = 0;
+    float t, h = 0.0f;
+    sparsemax_row(z, red, s, t);
+    if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
+    if (live) {
+        store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
+        if (gl == 0) {
+            supp[row] = s;
+            if constexpr (EXTRA) {
+                if (nnz) nnz[row] = n;
+                if (tau) tau[row] = t;
+                if (ent) ent[row] = h;
+            }
+        }
+    }
+}
+
+template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
+__global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
+    const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
+    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent, int64_t R, int K)
+{
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        float z[E];
+        load_row<E, VEC, FULL>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
+        BlockRed<NW> red(lds);
+        int s, n = 0;
+        float t, h = 0.0f;
+        sparsemax_row(z, red, s, t);
+        if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
+        store_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, z);
+        if (threadIdx.x == 0) {
+            supp[row] = s;
+            if constexpr (EXTRA) {
+                if (nnz) nnz[row] = n;
+                if (tau) tau[row] = t;
+                if (ent) ent[row] = h;
+            }
+        }
+        __syncthreads();  // LDS slots are reused by the next row
+    }
+}
+
+template <int E, class Red>
+__device__ __forceinline__ void bwd_row(float (&g)[E], const float (&pv)[E], int s, Red& red)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc += (pv[e] != 0.0f) ? (double)g[e] : 0.0;
+    acc = red.sum(acc);
+    const float v = (float)acc / (float)s;
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = (pv[e] != 0.0f) ? (g[e] - v) : 0.0f;
+}
+
+template <int G, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void sparsemax_bwd_wave_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ supp,
+    float* __restrict__ dx, int64_t R, int K)
+{
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % G;
+    int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < R;
+    if (!live) row = R - 1;
+    float g[E], pv[E];
+    load_row<E, VEC, FULL>(p + row * K, K, gl, G, pv, 0.0f);
+    load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+    WaveRed<G> red;
+    bwd_row(g, pv, supp[row], red);
+    if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
+}
+
+template <int NW, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * NW) void sparsemax_bwd_block_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ supp,
+    float* __restrict__ dx, int64_t R, int K)
+{
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        float g[E], pv[E];
+        load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, pv, 0.0f);
+        load_row<E, VEC, FULL>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
+        BlockRed<NW> red(lds);
+        bwd_row(g, pv, supp[row], red);
+        store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, g);
+        __syncthreads();
+    }
+}
+
+// Entropy of an arbitrary [R,K] probability matrix (used when the normaliser is not ours):
+// one wave per row, strided over K.
+__global__ __launch_bounds__(256) void entropy_kernel(const float* __restrict__ p,
+                                                      float* __restrict__ ent, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;  // whole wave leaves together
+    const float* pr = p + row * K;
+    double acc = 0.0;
+    for (int c = lane; c < K; c += 64) {
+        float v = pr[c];
+        if (v > 0.0f) {
+            float pc = fminf(fmaxf(v, FLT_EPSILON), 1.0f - FLT_EPSILON);
+            acc += (double)(pc * logf(pc));
+        }
+    }
+    acc = group_reduce<64>(acc, OpSum{});
+    if (lane == 0) ent[row] = -(float)acc;
+}
+
+// ------------------------------------------------------------------------------- dispatch
+struct FwdArgs {
+    const float* x; float* p; int32_t* supp; int32_t* nnz; float* tau; float* ent;
+    int64_t R; int K; hipStream_t st;
+    bool vec, extra;
+};
+struct BwdArgs {
+    const float* dy; const float* p; const int32_t* supp; float* dx;
+    int64_t R; int K; hipStream_t st;
+    bool vec;
+};
+
+static unsigned wave_grid(int64_t R, int G)
+{
+    const int64_t rows_per_block = (int64_t)kWavesPerBlock * (64 / G);
+    return (unsigned)((R + rows_per_block - 1) / rows_per_block);
+}
+static unsigned block_grid(int64_t R) { return (unsigned)(R < 65536 ? R : 65536); }
+
+template <int G, int E, bool VEC, bool FULL, bool EXTRA>
+static void fwd_wave_go(const FwdArgs& a)
+{
+    hipLaunchKernelGGL((sparsemax_fwd_wave_kernel<G, E, VEC, FULL, EXTRA>), dim3(wave_grid(a.R, G)),
+                       dim3(64 * kWavesPerBlock), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent,
+                       a.R, a.K);
+}
+template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
+static void fwd_block_go(const FwdArgs& a)
+{
+    hipLaunchKernelGGL((sparsemax_fwd_block_kernel<NW, E, VEC, FULL, EXTRA>), dim3(block_grid(a.R)),
+                       dim3(64 * NW), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent, a.R, a.K);
+}
+template <int G, int E, bool VEC, bool FULL>
+static void bwd_wave_go(const BwdArgs& a)
+{
+    hipLaunchKernelGGL((sparsemax_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
+                       dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
+}
+template <int NW, int E, bool VEC, bool FULL>
+static void bwd_block_go(const BwdArgs& a)
+{
+    hipLaunchKernelGGL((sparsemax_bwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)),
+                       dim3(64 * NW), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
+}
+
+// mode selection for one tile shape (A = lanes per row, or waves per row for the block kernels)
+template <int A, int E>
+static void launch_fwd_wave(const FwdArgs& a)
+{
+    const bool full = a.vec && a.K == A * E;
+    if (!a.vec)      a.extra ? fwd_wave_go<A, E, false, false, true>(a) : fwd_wave_go<A, E, false, false, false>(a);
+    else if (full)   a.extra ? fwd_wave_go<A, E, true, true, true>(a)   : fwd_wave_go<A, E, true, true, false>(a);
+    else             a.extra ? fwd_wave_go<A, E, true, false, true>(a)  : fwd_wave_go<A, E, true, false, false>(a);
+}
+template <int A, int E>
+static void launch_fwd_block(const FwdArgs& a)
+{
+    const bool full = a.vec && a.K == 64 * A * E;
+    if (!a.vec)      a.extra ? fwd_block_go<A, E, false, false, true>(a) : fwd_block_go<A, E, false, false, false>(a);
+    else if (full)   a.extra ? fwd_block_go<A, E, true, true, true>(a)   : fwd_block_go<A, E, true, true, false>(a);
+    else             a.extra ? fwd_block_go<A, E, true, false, true>(a)  : fwd_block_go<A, E, true, false, false>(a);
+}
+template <int A, int E>
+static void launch_bwd_wave(const BwdArgs& a)
+{
+    const bool full = a.vec && a.K == A * E;
+    if (!a.vec)    bwd_wave_go<A, E, false, false>(a);
+    else if (full) bwd_wave_go<A, E, true, true>(a);
+    else           bwd_wave_go<A, E, true, false>(a);
+}
+template <int A, int E>
+static void launch_bwd_block(const BwdArgs& a)
+{
+    const bool full = a.vec && a.K == 64 * A * E;
+    if (!a.vec)    bwd_block_go<A, E, false, false>(a);
+    else if (full) bwd_block_go<A, E, true, true>(a);
+    else           bwd_block_go<A, E, true, false>(a);
+}
+
+// Shape table: smallest register tile whose capacity covers K.
+#define SMLVM_DISPATCH(WAVE, BLOCK, args)                                                       \
+    do {                                                                                        \
+        const int K_ = (args).K;                                                                \
+        if (K_ <= 32) WAVE<8, 4>(args);                                                         \
+        else if (K_ <= 128) WAVE<8, 16>(args);                                                  \
+        else if (K_ <= 256) WAVE<16, 16>(args);                                                 \
+        else if (K_ <= 512) WAVE<32, 16>(args);                                                 \
+        else if (K_ <= 1024) WAVE<64, 16>(args);                                                \
+        else if (K_ <= 2048) WAVE<64, 32>(args);                                                \
+        else if (K_ <= 4096) WAVE<64, 64>(args);                                                \
+        else if (K_ <= 8192) BLOCK<2, 64>(args);                                                \
+        else if (K_ <= 16384) BLOCK<4, 64>(args);                                               \
+        else if (K_ <= 32768) BLOCK<8, 64>(args);                                               \
+        else BLOCK<16, 64>(args);                                                               \
+    } while (0)
+
+}  // namespace smlvm
+
+using namespace smlvm;
+
+extern "C" int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size, int32_t* nnz,
+                                   float* tau, float* entropy, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy};
+    SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_size,
+                                   float* dx, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx)};
+    SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!p || !ent) return SMLVM_ERR_INVALID;
+    hipLaunchKernelGGL(entropy_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, p, ent, R, K);
+    return check_launch();
+}

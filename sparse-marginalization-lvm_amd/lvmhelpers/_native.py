@@ -1,0 +1,254 @@
+"""ctypes binding of ``libsparsemarg_hip.so`` (C ABI: ``include/sparsemarg.h``) for torch tensors.
+
+PyTorch is only plumbing here: it owns device memory and the current HIP stream; every function
+below hands raw device pointers, sizes and that stream to the C ABI and returns torch tensors that
+wrap the outputs.  There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsparsemarg_hip.so")
+
+_lib = None
+
+ABI_SYMBOLS = [
+    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error",
+    "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_entropy",
+    "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
+    "smlvm_support_compact", "smlvm_weighted_loss_reduce_workspace_bytes",
+    "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
+    "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd", "smlvm_sparsemap_bwd",
+    "smlvm_unpack_configs",
+]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library (once). Raises NativeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C sparse-marginalization-lvm_amd/csrc`). There is no "
+                "CPU fallback for the hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.smlvm_error_string.restype = ctypes.c_char_p
+        L.smlvm_support_offsets_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
+        L.smlvm_weighted_loss_reduce_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_weighted_loss_reduce_workspace_bytes.argtypes = [ctypes.c_int64]
+        if L.smlvm_abi_version() != 1:
+            raise NativeError("libsparsemarg_hip.so: ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = lib()
+        msg = L.smlvm_error_string(rc).decode()
+        raise NativeError(f"{what}: {msg} (code {rc}, hip error {L.smlvm_last_hip_error()})")
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t, dtype, name):
+    if not t.is_cuda:
+        raise NativeError(f"{name}: expected a GPU tensor (the hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_f32 = ctypes.c_float
+
+
+# ----------------------------------------------------------------------------------- sparsemax
+def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False):
+    """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None)."""
+    x = _need_gpu(x, torch.float32, "x")
+    R, K = x.shape
+    p = torch.empty_like(x)
+    supp = torch.empty(R, dtype=torch.int32, device=x.device)
+    nnz = torch.empty(R, dtype=torch.int32, device=x.device) if want_nnz else None
+    tau = torch.empty(R, dtype=torch.float32, device=x.device) if want_tau else None
+    ent = torch.empty(R, dtype=torch.float32, device=x.device) if want_entropy else None
+    with torch.cuda.device(x.device):
+        _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
+                                         _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
+    return p, supp, nnz, tau, ent
+
+
+def sparsemax_bwd(dy, p, supp):
+    dy = _need_gpu(dy, torch.float32, "dy")
+    p = _need_gpu(p, torch.float32, "p")
+    supp = _need_gpu(supp, torch.int32, "supp_size")
+    R, K = p.shape
+    dx = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_sparsemax_bwd(_p(dy), _p(p), _p(supp), _p(dx), _i64(R), _i32(K),
+                                         _stream()), "smlvm_sparsemax_bwd")
+    return dx
+
+
+def entropy(p):
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    out = torch.empty(R, dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_entropy(_p(p), _p(out), _i64(R), _i32(K), _stream()), "smlvm_entropy")
+    return out
+
+
+# ----------------------------------------------------------------------------------- compaction
+def support_count(p):
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    nnz = torch.empty(R, dtype=torch.int32, device=p.device)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_support_count(_p(p), _p(nnz), _i64(R), _i32(K), _stream()),
+               "smlvm_support_count")
+    return nnz
+
+
+def support_offsets(nnz):
+    nnz = _need_gpu(nnz, torch.int32, "nnz")
+    R = nnz.shape[0]
+    off = torch.empty(R + 1, dtype=torch.int64, device=nnz.device)
+    nbytes = lib().smlvm_support_offsets_workspace_bytes(R)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=nnz.device)
+    with torch.cuda.device(nnz.device):
+        _check(lib().smlvm_support_offsets(_p(nnz), _p(off), _i64(R), _p(ws),
+                                           ctypes.c_size_t(nbytes), _stream()),
+               "smlvm_support_offsets")
+    return off
+
+
+def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True):
+    """Row-major (rows, cols, vals) lists of the positive entries of p [R,K] plus row_offsets.
+
+    One host sync (reading N = row_offsets[R]) to size the outputs.
+    """
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    if nnz is None:
+        nnz = support_count(p)
+    off = support_offsets(nnz)
+    N = int(off[R].item())
+    dev = p.device
+    rows = torch.empty(N, dtype=torch.int32, device=dev) if want_rows else None
+    cols = torch.empty(N, dtype=torch.int32, device=dev) if want_cols else None
+    vals = torch.empty(N, dtype=torch.float32, device=dev) if want_vals else None
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_support_compact(_p(p), _p(off), _p(rows), _p(cols), _p(vals), _i64(R),
+                                           _i32(K), _stream()), "smlvm_support_compact")
+    return off, rows, cols, vals
+
+
+def weighted_loss_reduce_fwd(vals, comps, row_offsets=None, inv_b=1.0, want_rows=False):
+    vals = _need_gpu(vals, torch.float32, "vals")
+    comps = _need_gpu(comps, torch.float32, "comps")
+    N = vals.shape[0]
+    if comps.shape[0] != N:
+        raise ValueError("vals and comps must have the same length")
+    dev = vals.device
+    R = 0 if row_offsets is None else row_offsets.shape[0] - 1
+    row_out = torch.empty(R, dtype=torch.float32, device=dev) if (want_rows and R > 0) else None
+    total = torch.empty(1, dtype=torch.float32, device=dev)
+    nbytes = lib().smlvm_weighted_loss_reduce_workspace_bytes(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_weighted_loss_reduce_fwd(
+            _p(vals), _p(comps), _p(row_offsets), _p(row_out), _p(total), _f32(inv_b), _i64(R),
+            _i64(N), _p(ws), ctypes.c_size_t(nbytes), _stream()), "smlvm_weighted_loss_reduce_fwd")
+    return total, row_out
+
+
+def weighted_loss_reduce_bwd(vals, comps, gtotal, inv_b, want_dvals=True, want_dcomps=True):
+    vals = _need_gpu(vals, torch.float32, "vals")
+    comps = _need_gpu(comps, torch.float32, "comps")
+    gtotal = _need_gpu(gtotal.reshape(1), torch.float32, "gtotal")
+    N = vals.shape[0]
+    dvals = torch.empty_like(vals) if want_dvals else None
+    dcomps = torch.empty_like(comps) if want_dcomps else None
+    with torch.cuda.device(vals.device):
+        _check(lib().smlvm_weighted_loss_reduce_bwd(_p(vals), _p(comps), _p(gtotal), _f32(inv_b),
+                                                    _p(dvals), _p(dcomps), _i64(N), _stream()),
+               "smlvm_weighted_loss_reduce_bwd")
+    return dvals, dcomps
+
+
+# ----------------------------------------------------------------------------------- top-k
+def binary_topk_batched(scores, k, want_scores=False):
+    scores = _need_gpu(scores, torch.float32, "scores")
+    B, n = scores.shape
+    cfg = torch.empty((B, k, n), dtype=torch.float32, device=scores.device)
+    top = torch.empty((B, k), dtype=torch.float32, device=scores.device) if want_scores else None
+    with torch.cuda.device(scores.device):
+        _check(lib().smlvm_binary_topk_batched(_p(scores), _p(cfg), _p(top), _i64(B), _i32(n),
+                                               _i32(k), _stream()), "smlvm_binary_topk_batched")
+    return cfg, top
+
+
+# ----------------------------------------------------------------------------------- SparseMAP
+def sparsemap_fwd(scores, init_scores=None, budget=0, max_iter=300):
+    """scores [B,n] f32 (GPU), init_scores [B,2n] f64 (GPU) or None.
+
+    Returns dict(aset_bits [B,cap,W] i32 (bit pattern of uint32), p [B,cap] f32, alen [B] i32,
+    inv_a [B,ld,ld] f64, iters [B] i32, status [B] i32).
+    """
+    scores = _need_gpu(scores, torch.float32, "scores")
+    B, n = scores.shape
+    cap, W, ld = n + 1, (n + 31) // 32, n + 2
+    dev = scores.device
+    if init_scores is not None:
+        init_scores = _need_gpu(init_scores, torch.float64, "init_scores")
+        if tuple(init_scores.shape) != (B, 2 * n):
+            raise ValueError("init_scores must be [B, 2n]")
+    out = dict(
+        aset_bits=torch.empty((B, cap, W), dtype=torch.int32, device=dev),
+        p=torch.empty((B, cap), dtype=torch.float32, device=dev),
+        alen=torch.empty(B, dtype=torch.int32, device=dev),
+        inv_a=torch.empty((B, ld, ld), dtype=torch.float64, device=dev),
+        iters=torch.empty(B, dtype=torch.int32, device=dev),
+        status=torch.empty(B, dtype=torch.int32, device=dev))
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_sparsemap_fwd(
+            _p(scores), _p(init_scores), _i32(int(budget)), _i32(int(max_iter)), _i64(B), _i32(n),
+            _p(out["aset_bits"]), _p(out["p"]), _p(out["alen"]), _p(out["inv_a"]),
+            _p(out["iters"]), _p(out["status"]), _stream()), "smlvm_sparsemap_fwd")
+    return out
+
+
+def sparsemap_bwd(dp, aset_bits, alen, inv_a, n):
+    dp = _need_gpu(dp, torch.float32, "dp")
+    B = dp.shape[0]
+    dscores = torch.empty((B, n), dtype=torch.float32, device=dp.device)
+    with torch.cuda.device(dp.device):
+        _check(lib().smlvm_sparsemap_bwd(_p(dp), _p(aset_bits), _p(alen), _p(inv_a), _i64(B),
+                                         _i32(n), _p(dscores), _stream()), "smlvm_sparsemap_bwd")
+    return dscores
+
+
+def unpack_configs(aset_bits, rows, cols, n):
+    N = rows.shape[0]
+    out = torch.empty((N, n), dtype=torch.float32, device=aset_bits.device)
+    with torch.cuda.device(aset_bits.device):
+        _check(lib().smlvm_unpack_configs(_p(aset_bits), _p(rows), _p(cols), _p(out), _i64(N),
+                                          _i32(n), _stream()), "smlvm_unpack_configs")
+    return out

@@ -1,0 +1,134 @@
+"""torch.autograd glue over the C-ABI kernels (``_native``).  Host-side plumbing only."""
+import torch
+
+from . import _native
+
+
+class _Sparsemax(torch.autograd.Function):
+    """Row-wise sparsemax over the last dim (replaces entmax.sparsemax; marg.py:45,51)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        shape = x.shape
+        p, supp, _, _, _ = _native.sparsemax_fwd(x.reshape(-1, shape[-1]))
+        ctx.save_for_backward(p, supp)
+        return p.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, supp = ctx.saved_tensors
+        dx = _native.sparsemax_bwd(dy.reshape(p.shape), p, supp)
+        return dx.view(dy.shape)
+
+
+class _SparsemaxEntropy(torch.autograd.Function):
+    """Fused sparsemax + Shannon entropy (marg.py:51-52): one forward kernel, one backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        p, supp, _, _, ent = _native.sparsemax_fwd(x, want_entropy=True)
+        ctx.save_for_backward(p, supp)
+        ctx.mark_non_differentiable(supp)
+        return p, ent, supp
+
+    @staticmethod
+    def backward(ctx, dp, dent, _dsupp):
+        p, supp = ctx.saved_tensors
+        if dp is None and dent is None:
+            return torch.zeros_like(p)
+        if dent is None:
+            g = dp
+        elif dp is None:
+            g = _entropy_vjp(p, dent)
+        else:
+            g = dp + _entropy_vjp(p, dent)
+        return _native.sparsemax_bwd(g.contiguous(), p, supp)
+
+
+def _entropy_vjp(p, dent):
+    # d/dp of -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps): the clamp passes gradient only
+    # inside [eps, 1-eps] (marg.py:18-28)
+    eps = torch.finfo(p.dtype).eps
+    inside = (p >= eps) & (p <= 1 - eps)
+    safe = torch.where(inside, p, torch.ones_like(p))
+    return torch.where(inside, -(safe.log() + 1.0), torch.zeros_like(p)) * dent.unsqueeze(-1)
+
+
+class _Entropy(torch.autograd.Function):
+    """lvmhelpers/marg.py:6-28 on an arbitrary probability matrix."""
+
+    @staticmethod
+    def forward(ctx, p):
+        ctx.save_for_backward(p)
+        return _native.entropy(p)
+
+    @staticmethod
+    def backward(ctx, dent):
+        (p,) = ctx.saved_tensors
+        return _entropy_vjp(p, dent)
+
+
+class _WeightedLossReduce(torch.autograd.Function):
+    """inv_b * <vals, comps> with the fused deterministic reduction kernel (marg.py:125-126,
+    structmarg.py:140,242)."""
+
+    @staticmethod
+    def forward(ctx, vals, comps, inv_b):
+        total, _ = _native.weighted_loss_reduce_fwd(vals, comps, None, inv_b)
+        ctx.save_for_backward(vals, comps)
+        ctx.inv_b = inv_b
+        return total.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        vals, comps = ctx.saved_tensors
+        dv, dc = _native.weighted_loss_reduce_bwd(
+            vals, comps, g.to(torch.float32), ctx.inv_b,
+            want_dvals=ctx.needs_input_grad[0], want_dcomps=ctx.needs_input_grad[1])
+        return dv, dc, None
+
+
+class _SparseMAP(torch.autograd.Function):
+    """Batched bit-vector SparseMAP (sparsemap.py:12-44 for every sample of the batch at once)."""
+
+    @staticmethod
+    def forward(ctx, scores, init_scores, budget, max_iter):
+        out = _native.sparsemap_fwd(scores.detach(), init_scores, budget, max_iter)
+        ctx.n = scores.shape[1]
+        ctx.save_for_backward(out["aset_bits"], out["alen"], out["inv_a"])
+        for k in ("aset_bits", "alen", "iters", "status"):
+            ctx.mark_non_differentiable(out[k])
+        return out["p"], out["aset_bits"], out["alen"], out["iters"], out["status"]
+
+    @staticmethod
+    def backward(ctx, dp, *_):
+        aset_bits, alen, inv_a = ctx.saved_tensors
+        return _native.sparsemap_bwd(dp.contiguous(), aset_bits, alen, inv_a, ctx.n), None, None, None
+
+
+def sparsemax(X, dim=-1):
+    """entmax.sparsemax replacement: Euclidean projection of each slice along `dim` onto the simplex."""
+    if dim < 0:
+        dim += X.dim()
+    if dim != X.dim() - 1:
+        return _Sparsemax.apply(X.transpose(dim, -1).contiguous()).transpose(dim, -1)
+    return _Sparsemax.apply(X.contiguous())
+
+
+def sparsemax_with_entropy(X):
+    """X [B,K] -> (p [B,K], entropy [B], supp_size [B] int32)."""
+    return _SparsemaxEntropy.apply(X.contiguous())
+
+
+def entropy(p):
+    return _Entropy.apply(p.contiguous())
+
+
+def weighted_loss(vals, comps, inv_b):
+    """inv_b * sum_j vals[j]*comps[j] as a 0-d tensor (differentiable in both)."""
+    return _WeightedLossReduce.apply(vals.contiguous(), comps.contiguous(), float(inv_b))
+
+
+def sparsemap_batched(scores, init_scores=None, budget=0, max_iter=300):
+    """scores [B,n] -> (p [B,n+1] differentiable, aset_bits, alen, iters, status)."""
+    return _SparseMAP.apply(scores.contiguous(), init_scores, int(budget), int(max_iter))

@@ -1,0 +1,114 @@
+"""Exact marginalisation over a categorical latent (drop-in for lvmhelpers/marg.py).
+
+Same public surface as the reference (marg.py:6,31-54,57-132); the arithmetic of the hot path --
+sparsemax forward/backward, entropy, the probability-weighted loss reduction -- runs in the
+gfx950 kernels behind ``include/sparsemarg.h``.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+
+
+def entropy(p: torch.Tensor):
+    """Shannon entropy of each row of ``p`` [batch, categories], exact zeros allowed
+    (reference: lvmhelpers/marg.py:6-28).  Returns [batch]."""
+    return F_.entropy(p)
+
+
+def _entmax15(X, dim=-1):
+    from entmax import entmax15  # the shim shipped next to this package
+    return entmax15(X, dim=dim)
+
+
+class ExplicitWrapper(nn.Module):
+    """Wraps a scoring network: ``forward`` returns ``(argmax sample [B], distr [B,K],
+    entropy [B])`` (reference: lvmhelpers/marg.py:31-54)."""
+
+    def __init__(self, agent, normalizer='entmax'):
+        super().__init__()
+        self.agent = agent
+        # KeyError for an unknown name, like the reference's dict lookup (marg.py:43-47)
+        self.normalizer = {
+            'softmax': torch.softmax,
+            'sparsemax': F_.sparsemax,
+            'entmax': _entmax15}[normalizer]
+        self._fused = normalizer == 'sparsemax'
+
+    def forward(self, *args, **kwargs):
+        scores = self.agent(*args, **kwargs)
+        if self._fused and scores.dim() == 2:
+            # one kernel: sparsemax + entropy epilogue
+            distr, entropy_distr, _ = F_.sparsemax_with_entropy(scores)
+        else:
+            distr = self.normalizer(scores, dim=-1)
+            entropy_distr = entropy(distr)
+        sample = scores.argmax(dim=-1)
+        return sample, distr, entropy_distr
+
+
+class Marginalizer(torch.nn.Module):
+    """Training loop of the exact-marginalisation estimator (reference: lvmhelpers/marg.py:57-132).
+
+    ``encoder`` is an ExplicitWrapper, ``decoder`` a DeterministicWrapper, ``loss_fun(encoder_input,
+    z, decoder_input, decoder_output, labels) -> (per-row loss [B], dict)``.
+
+    The decoder is run on the full batch once per latent value that is live for at least one row,
+    exactly like the reference, but the live set is read back with ONE host sync instead of one per
+    category (marg.py:87), and ``sum_z p(z|x) * loss_z`` is the fused weighted-reduction kernel.
+    """
+
+    def __init__(
+            self,
+            encoder,
+            decoder,
+            loss_fun,
+            encoder_entropy_coeff=0.0,
+            decoder_entropy_coeff=0.0):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.loss = loss_fun
+        self.encoder_entropy_coeff = encoder_entropy_coeff
+        self.decoder_entropy_coeff = decoder_entropy_coeff
+
+    def forward(self, encoder_input, decoder_input, labels):
+        discrete_latent_z, encoder_probs, encoder_entropy = self.encoder(encoder_input)
+        batch_size, latent_size = encoder_probs.shape
+        entropy_loss = -(encoder_entropy.mean() * self.encoder_entropy_coeff)
+
+        # columns whose probability mass is non-zero for some row (marg.py:87), one sync
+        live = (encoder_probs.detach().sum(dim=0) != 0).nonzero().flatten().tolist()
+
+        column_losses = []
+        logs, logs_global = None, None
+        for z in live:
+            z_batch = torch.full((batch_size,), z, dtype=torch.long, device=encoder_probs.device)
+            decoder_output = self.decoder(z_batch, decoder_input)
+            # NB the reference hands the ARGMAX sample to the loss, not z (marg.py:98-100)
+            loss_z, logs = self.loss(
+                encoder_input, discrete_latent_z, decoder_input, decoder_output, labels)
+            column_losses.append(loss_z)
+            if not logs_global:
+                logs_global = {k: 0.0 for k in logs.keys()}
+            for k, v in logs.items():
+                if hasattr(v, 'mean'):
+                    logs_global[k] += (encoder_probs[:, z] * v).mean()
+        if logs is None:
+            raise RuntimeError("Marginalizer: the encoder distribution has no live category")
+        for k, v in logs.items():
+            if hasattr(v, 'mean'):
+                logs[k] = logs_global[k]
+
+        # mean_b sum_z p[b,z] * loss[b,z] over the live columns (the others contribute 0)
+        losses = torch.stack(column_losses, dim=1)                      # [B, |live|]
+        probs_live = encoder_probs[:, live] if len(live) < latent_size else encoder_probs
+        loss_mean = F_.weighted_loss(
+            probs_live.reshape(-1), losses.reshape(-1).to(encoder_probs.dtype), 1.0 / batch_size)
+        full_loss = loss_mean + entropy_loss.mean()
+
+        logs['loss'] = loss_mean
+        logs['encoder_entropy'] = encoder_entropy.mean()
+        logs['support'] = (encoder_probs != 0).sum(-1).to(torch.float).mean()
+        logs['distr'] = encoder_probs
+        return {'loss': full_loss, 'log': logs}

@@ -1,0 +1,187 @@
+"""Structured (bit-vector) marginalisation: top-k sparsemax and SparseMAP
+(drop-in for lvmhelpers/structmarg.py).
+
+Public surface as in the reference (structmarg.py:23-58, 61-153, 156-202, 205-255).  What runs
+where: k-best enumeration, sparsemax, support compaction, bit unpacking, the batched active-set
+solver and the weighted loss reduction are gfx950 kernels; encoder/decoder networks and the user
+loss stay PyTorch-ROCm ops.
+"""
+import torch
+import torch.nn as nn
+
+from . import _native
+from . import functional as F_
+
+
+def entropy(p):
+    """Same function as lvmhelpers.marg.entropy (the reference keeps a copy: structmarg.py:9-20)."""
+    return F_.entropy(p)
+
+
+def _support_entropy(p):
+    """-sum_{p>0} p log p, no clamping (structmarg.py:51-54, 200)."""
+    safe = torch.where(p > 0, p, torch.ones_like(p))
+    return -(p * safe.log()).sum()
+
+
+class TopKSparsemaxWrapper(nn.Module):
+    """Scores [B,n] -> (k best bit vectors [B,k,n], sparsemax over their scores [B,k], entropy/B)
+    (reference: lvmhelpers/structmarg.py:23-58)."""
+
+    def __init__(self, agent, k=10):
+        super().__init__()
+        self.agent = agent
+        self.k = k
+
+    def forward(self, *args, **kwargs):
+        scores = self.agent(*args, **kwargs)
+        batch_size, latent_size = scores.shape
+        # k-best enumeration stays on the device (the reference round-trips through the host,
+        # structmarg.py:42-44)
+        bit_vector_z, _ = _native.binary_topk_batched(scores.detach(), self.k)
+        topk_scores = torch.einsum("bkj,bj->bk", bit_vector_z, scores)
+        distr = F_.sparsemax(topk_scores, dim=-1)
+        entropy_distr = _support_entropy(distr)
+        return bit_vector_z, distr, entropy_distr / batch_size
+
+
+class TopKSparsemaxMarg(torch.nn.Module):
+    """Training loop of the top-k sparsemax estimator (reference: lvmhelpers/structmarg.py:61-153).
+
+    The reference repeats every input k times and boolean-masks the copies; here the compaction
+    kernel emits the (row, slot) lists of the non-zero probabilities in the same row-major order
+    and the inputs are gathered by row.
+    """
+
+    def __init__(
+            self,
+            encoder,
+            decoder,
+            loss_fun,
+            encoder_entropy_coeff=0.0,
+            decoder_entropy_coeff=0.0):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.loss = loss_fun
+        self.encoder_entropy_coeff = encoder_entropy_coeff
+        self.decoder_entropy_coeff = decoder_entropy_coeff
+
+    def forward(self, encoder_input, decoder_input, labels):
+        bit_vector_z, encoder_probs, encoder_entropy = self.encoder(encoder_input)
+        batch_size, k, latent_size = bit_vector_z.shape
+        entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
+
+        # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
+        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False)
+        rows_l, cols_l = rows.long(), cols.long()
+        encoder_input_sel = encoder_input[rows_l]
+        decoder_input_sel = decoder_input[rows_l]
+        labels_sel = labels[rows_l]
+        probs_sel = encoder_probs[rows_l, cols_l]
+        bit_vector_z_flat = bit_vector_z[rows_l, cols_l]
+
+        decoder_output = self.decoder(bit_vector_z_flat, decoder_input)
+        loss_components, logs = self.loss(
+            encoder_input_sel, bit_vector_z_flat, decoder_input_sel, decoder_output, labels_sel)
+
+        loss = F_.weighted_loss(probs_sel, loss_components.to(probs_sel.dtype), 1.0 / batch_size)
+        full_loss = loss.mean() + entropy_loss
+
+        for key, v in logs.items():
+            if hasattr(v, 'mean'):
+                logs[key] = v.mean()
+        logs['loss'] = loss.mean().detach()
+        logs['encoder_entropy'] = encoder_entropy.detach()
+        logs['support'] = (encoder_probs > 0).sum(dim=-1).to(torch.float)
+        logs['distr'] = encoder_probs
+        logs['loss_output'] = loss_components
+        return {'loss': full_loss, 'log': logs}
+
+
+class SparseMAPWrapper(nn.Module):
+    """Scores [B,n] -> SparseMAP distribution over bit vectors, for the whole batch in one launch
+    (reference: lvmhelpers/structmarg.py:156-202, which loops over samples in Python).
+
+    Returns ``(sample [N,n], distr [N], entropy/B, idxs: list[int] of length N, support: list[int]
+    of length B)`` in batch order, then active-set order, entries with p <= 0 dropped.
+    """
+
+    def __init__(self, agent, budget=0, init=False, max_iter=300):
+        super().__init__()
+        self.agent = agent
+        self.budget = budget
+        self.init = init
+        self.max_iter = max_iter
+        self._idx_tensor = None
+
+    def forward(self, *args, **kwargs):
+        scores = self.agent(*args, **kwargs)
+        batch_size, latent_size = scores.shape
+        init_scores = None
+        if self.init:
+            # the reference draws torch.rand(2n, dtype=double) from the global CPU generator once
+            # per sample (sparsemap.py:25-27); one [B, 2n] draw consumes the same stream
+            init_scores = torch.rand(
+                batch_size, 2 * latent_size, dtype=torch.double).to(scores.device)
+        p, aset_bits, alen, _, _ = F_.sparsemap_batched(
+            scores, init_scores, self.budget, self.max_iter)
+
+        off, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False)
+        support = (off[1:] - off[:-1]).tolist()
+        assert min(support) > 0
+        rows_l = rows.long()
+        sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
+        distr = p[rows_l, cols.long()]
+        entropy_distr = _support_entropy(distr)
+        self._idx_tensor = rows_l
+        return sample, distr, entropy_distr / batch_size, rows_l.tolist(), support
+
+
+class SparseMAPMarg(torch.nn.Module):
+    """Training loop of the SparseMAP estimator (reference: lvmhelpers/structmarg.py:205-255)."""
+
+    def __init__(
+            self,
+            encoder,
+            decoder,
+            loss_fun,
+            encoder_entropy_coeff=0.0,
+            decoder_entropy_coeff=0.0):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.loss = loss_fun
+        self.encoder_entropy_coeff = encoder_entropy_coeff
+        self.decoder_entropy_coeff = decoder_entropy_coeff
+
+    def forward(self, encoder_input, decoder_input, labels):
+        bit_vector_z, encoder_probs, encoder_entropy, idxs, support = \
+            self.encoder(encoder_input)
+        batch_size = encoder_input.shape[0]
+        entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
+
+        # gather by the device-side index tensor when the encoder is ours (same values as `idxs`)
+        gather = getattr(self.encoder, '_idx_tensor', None)
+        if gather is None or gather.numel() != len(idxs):
+            gather = idxs
+
+        decoder_output = self.decoder(bit_vector_z)
+        loss_components, logs = self.loss(
+            encoder_input[gather], bit_vector_z, decoder_input[gather], decoder_output,
+            labels[gather])
+
+        loss = F_.weighted_loss(
+            encoder_probs, loss_components.to(encoder_probs.dtype), 1.0 / batch_size)
+        full_loss = loss + entropy_loss
+
+        for key, v in logs.items():
+            if hasattr(v, 'mean'):
+                logs[key] = v.mean()
+        logs['loss'] = loss.detach()
+        logs['encoder_entropy'] = encoder_entropy.detach()
+        logs['support'] = torch.tensor(support).to(torch.float)
+        logs['distr'] = encoder_probs.detach()
+        logs['loss_output'] = loss_components.detach()
+        logs['idxs'] = idxs
+        return {'loss': full_loss, 'log': logs}

@@ -1,0 +1,101 @@
+"""GPU parity of kernel 2 (support compaction, offsets, weighted reduction) and the k-best
+enumerator against the CPU oracle (bit-exact: integer/index work and fp32 index-order sums)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("R,K,density", [(64, 10, 0.3), (64, 256, 0.02), (1, 1, 1.0), (5, 3, 0.0),
+                                         (100, 129, 0.5), (7, 4096, 0.001), (3, 65536, 0.3),
+                                         (5000, 40, 0.1), (9, 1027, 1.0)])
+def test_compact_matches_oracle(dev, oracle_mod, R, K, density):
+    from lvmhelpers import _native
+    rng = np.random.default_rng(R * 131 + K)
+    p = rng.random((R, K)).astype(np.float32)
+    p[rng.random((R, K)) >= density] = 0.0
+    off_ref, rows_ref, cols_ref, vals_ref = oracle_mod.support_compact(p)
+    pt = torch.from_numpy(p).to(dev)
+    nnz = _native.support_count(pt)
+    assert np.array_equal(nnz.cpu().numpy(), np.diff(off_ref).astype(np.int32))
+    off, rows, cols, vals = _native.support_compact(pt)
+    assert np.array_equal(off.cpu().numpy(), off_ref)
+    assert np.array_equal(rows.cpu().numpy(), rows_ref)
+    assert np.array_equal(cols.cpu().numpy(), cols_ref)
+    assert np.array_equal(vals.cpu().numpy(), vals_ref)
+    # same order as torch's own boolean-mask / nonzero (lvmhelpers/structmarg.py:116-126)
+    nz = torch.nonzero(pt > 0)
+    assert torch.equal(nz[:, 0].to(torch.int32), rows) and torch.equal(nz[:, 1].to(torch.int32), cols)
+
+
+def test_offsets_large(dev):
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(5)
+    for R in (1, 255, 256, 2048, 2049, 1 << 20, (1 << 20) + 17):
+        nnz = torch.randint(0, 9, (R,), device=dev, generator=g, dtype=torch.int32)
+        off = _native.support_offsets(nnz)
+        ref = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        ref[1:] = torch.cumsum(nnz.to(torch.int64), 0)
+        assert torch.equal(off, ref)
+
+
+@pytest.mark.parametrize("N,R", [(0, 4), (5, 3), (640, 64), (100000, 777), (3000001, 1000)])
+def test_weighted_loss_reduce(dev, oracle_mod, N, R):
+    from lvmhelpers import _native, functional as F_
+    rng = np.random.default_rng(N + R)
+    vals = rng.random(N).astype(np.float32)
+    comps = (500 * rng.random(N)).astype(np.float32)
+    cuts = np.sort(rng.integers(0, N + 1, R - 1)) if R > 1 else np.zeros(0, np.int64)
+    off = np.concatenate([[0], cuts, [N]]).astype(np.int64)
+    out_ref, tot_ref = oracle_mod.weighted_loss_reduce(vals, comps, off, 1.0 / 64)
+    vt, ct = torch.from_numpy(vals).to(dev), torch.from_numpy(comps).to(dev)
+    total, rows = _native.weighted_loss_reduce_fwd(vt, ct, torch.from_numpy(off).to(dev), 1.0 / 64,
+                                                   want_rows=True)
+    np.testing.assert_allclose(total.item(), tot_ref, rtol=1e-6)
+    np.testing.assert_allclose(rows.cpu().numpy(), out_ref, rtol=1e-6, atol=1e-30)
+    if N:
+        vt.requires_grad_(True); ct.requires_grad_(True)
+        (3.0 * F_.weighted_loss(vt, ct, 1.0 / 64)).backward()
+        np.testing.assert_allclose(vt.grad.cpu().numpy(), 3.0 / 64 * comps, rtol=1e-6)
+        np.testing.assert_allclose(ct.grad.cpu().numpy(), 3.0 / 64 * vals, rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,n,k", [(64, 32, 10), (64, 128, 10), (8, 4, 16), (5, 1, 2), (3, 2, 4),
+                                   (16, 33, 2), (7, 64, 17), (4, 512, 64), (300, 20, 64),
+                                   (2, 5, 32), (1000, 128, 10)])
+def test_binary_topk_matches_oracle(dev, oracle_mod, B, n, k):
+    from lvmhelpers import _native
+    rng = np.random.default_rng(B + 17 * n + k)
+    scores = rng.standard_normal((B, n)).astype(np.float32)
+    scores[::3] = np.round(scores[::3] * 2) / 2          # ties
+    if B > 2:
+        scores[1] = 0.0                                   # all zero: every configuration ties
+    cfg_ref, top_ref = oracle_mod.binary_topk_batched(scores, k)
+    cfg, top = _native.binary_topk_batched(torch.from_numpy(scores).to(dev), k, want_scores=True)
+    assert np.array_equal(top.cpu().numpy(), top_ref)
+    assert np.array_equal(cfg.cpu().numpy(), cfg_ref)
+
+
+def test_binary_topk_rejects_undefined_cases(dev):
+    from lvmhelpers import _native
+    x = torch.zeros(2, 3, device=dev)
+    with pytest.raises(_native.NativeError):
+        _native.binary_topk_batched(x, 9)      # k > 2^n: UB in the reference
+    with pytest.raises(_native.NativeError):
+        _native.binary_topk_batched(x, 1)      # k < 2: UB in the reference
+    with pytest.raises(_native.NativeError):
+        _native.binary_topk_batched(torch.zeros(2, 40, device=dev), 65)
+
+
+def test_pbinary_topk_host_api(dev, oracle_mod):
+    from lvmhelpers import pbinary_topk
+    out = pbinary_topk.binary_topk([0.5, -1, 2, 0.1], 5)
+    assert [c for _, c in out] == [[1, 0, 1, 1], [1, 0, 1, 0], [0, 0, 1, 1], [0, 0, 1, 0], [1, 1, 1, 1]]
+    rng = np.random.default_rng(0)
+    scores = rng.standard_normal((64, 32)).astype(np.float32)
+    cfg = np.empty((64, 10, 32), np.float32)
+    pbinary_topk.batched_topk(scores, cfg, 10)
+    assert np.array_equal(cfg, oracle_mod.binary_topk_batched(scores, 10)[0])
+    with pytest.raises(ValueError):
+        pbinary_topk.batched_topk(scores.astype(np.float64), cfg, 10)

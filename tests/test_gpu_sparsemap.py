@@ -1,0 +1,95 @@
+"""GPU parity of kernel 3 (active-set SparseMAP) against the fp64 CPU oracle.
+
+Bar: active set (which configurations, in which order), its length, the iteration count and the
+exit status identical; p identical after the fp32 cast (the kernel mirrors the oracle's fp64
+operation order, so the fp64 values are the same bits); cached inverse identical; backward within
+1e-6 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(B, n, sigma, seed, kind="normal"):
+    rng = np.random.default_rng(seed)
+    x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+    if kind == "degenerate":
+        x = np.round(x)                        # integers: |x| >= 1 or exactly 0 -> ties everywhere
+        x[0] = 0.0
+        x[1 % B] = 1.0
+        x[2 % B] = -1.0
+    init = torch.rand(B, 2 * n, dtype=torch.double,
+                      generator=torch.Generator().manual_seed(42)).numpy()
+    return x, init
+
+
+CASES = [(64, 32, 1.0, 0, True), (64, 32, 1.0, 16, True), (64, 32, 3.0, 0, False),
+         (64, 32, 3.0, 16, False), (16, 128, 1.0, 0, True), (16, 128, 1.0, 64, True),
+         (16, 128, 3.0, 64, False), (8, 5, 1.0, 3, True), (8, 1, 1.0, 0, True),
+         (8, 33, 1.0, 5, True), (8, 64, 0.5, 0, False), (8, 100, 2.0, 10, True)]
+
+
+@pytest.mark.parametrize("kind", ["normal", "degenerate"])
+@pytest.mark.parametrize("B,n,sigma,budget,use_init", CASES)
+def test_fwd_bwd_match_oracle(dev, oracle_mod, B, n, sigma, budget, use_init, kind):
+    from lvmhelpers import _native
+    x, init = _inputs(B, n, sigma, 100 * n + budget, kind)
+    ref = oracle_mod.sparsemap_fwd(x, init if use_init else None, budget, 300)
+    out = _native.sparsemap_fwd(torch.from_numpy(x).to(dev),
+                                torch.from_numpy(init).to(dev) if use_init else None, budget, 300)
+    alen = out["alen"].cpu().numpy()
+    assert np.array_equal(alen, ref["alen"])
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    bits = out["aset_bits"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(bits, ref["aset_bits"])
+    assert np.array_equal(out["p"].cpu().numpy(), ref["p"])
+    inv = out["inv_a"].cpu().numpy()
+    for b in range(B):
+        m = alen[b]
+        assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
+    # backward
+    rng = np.random.default_rng(5)
+    dp = rng.standard_normal((B, n + 1)).astype(np.float32)
+    d_ref = oracle_mod.sparsemap_bwd(dp, ref["aset_bits"], ref["alen"], ref["invA"], n)
+    d = _native.sparsemap_bwd(torch.from_numpy(dp).to(dev), out["aset_bits"], out["alen"],
+                              out["inv_a"], n).cpu().numpy()
+    np.testing.assert_allclose(d, d_ref, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(d_ref).max()))
+
+
+def test_max_iter_is_respected(dev, oracle_mod):
+    from lvmhelpers import _native
+    x, init = _inputs(8, 64, 1.0, 9)
+    for mi in (0, 1, 2, 7, 50):
+        ref = oracle_mod.sparsemap_fwd(x, init, 0, mi)
+        out = _native.sparsemap_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(init).to(dev), 0, mi)
+        assert np.array_equal(out["alen"].cpu().numpy(), ref["alen"])
+        assert np.array_equal(out["p"].cpu().numpy(), ref["p"])
+        assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+
+
+def test_marginals_closed_form_full_size(dev):
+    """cfg5 shape (1024 samples/GPU at 128 bits): M p equals the closed-form marginals."""
+    from lvmhelpers import _native
+    B, n = 1024, 128
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(B, n, device=dev, generator=g) * 3
+    init = torch.rand(B, 2 * n, dtype=torch.double).to(dev)
+    out = _native.sparsemap_fwd(x, init, 0, 300)
+    ok = out["status"] == 0  # converged by the KKT test (value <= tau + 1e-9)
+    assert ok.float().mean() > 0.9
+    k = torch.arange(n, device=dev)
+    bits = ((out["aset_bits"][..., k // 32] >> (k % 32)) & 1).double()     # [B,cap,n]
+    mu = torch.einsum("bc,bcn->bn", out["p"].double(), bits)
+    mu_ref = ((x.double() + 1) / 2).clamp(0, 1)
+    err = (mu - mu_ref).abs().max(dim=-1)[0]
+    psum = (out["p"].double().sum(-1) - 1).abs()
+    # The published active-set method keeps a rank-one-updated inverse; near convergence it can
+    # insert an almost affinely dependent vertex (|s| barely above its 1e-9 test) and lose the
+    # inverse.  That is a property of the algorithm (the CPU oracle does the same, bit for bit),
+    # seen on <1% of samples at 128 bits with |scores| ~ 3; everything else is at the optimum.
+    good = ok & (psum < 1e-6)
+    assert good.float().mean() > 0.98
+    assert err[good].max() < 1e-4
+    assert torch.all(out["p"][good] >= -1e-7)

@@ -1,0 +1,138 @@
+"""GPU parity of kernel 1 (sparsemax fwd/bwd, fused entropy/nnz) against the CPU oracle.
+
+Bar: support (p > 0 pattern) and supp_size bit-exact; tau and p bit-exact (the kernel reproduces the
+oracle's fp32 expressions from an fp64 candidate sum); gradients within 1e-6 relative of the row
+scale (summation order of the masked row sum differs)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 10), (64, 256), (7, 3), (5, 1), (33, 31), (64, 32), (19, 100), (16, 128), (130, 200),
+          (9, 512), (6, 1000), (5, 1024), (4, 1500), (3, 2048), (3, 4096), (3, 4100), (2, 8192),
+          (2, 10000), (2, 16384), (2, 32768), (2, 65536), (1, 50001)]
+
+
+def _rows(rng, R, K, kind):
+    if kind == "normal":
+        return rng.standard_normal((R, K)).astype(np.float32)
+    if kind == "narrow":
+        return (0.05 * rng.standard_normal((R, K))).astype(np.float32)
+    if kind == "wide":
+        return (10 * rng.standard_normal((R, K))).astype(np.float32)
+    if kind == "adversarial":
+        x = rng.standard_normal((R, K)).astype(np.float32)
+        for r in range(R):
+            m = r % 6
+            if m == 0:
+                x[r] = 0.25                      # all equal -> support K
+            elif m == 1:
+                x[r] = -1.0; x[r, r % K] = 3.0   # one dominant logit -> support 1
+            elif m == 2:
+                x[r] = -1.0; x[r, 0] = 0.0       # exact tie at the threshold (tau = -1)
+            elif m == 3:
+                x[r] = np.round(x[r] * 4) / 4    # many exact ties
+            elif m == 4:
+                x[r, : max(1, K // 2)] = 1.0     # half the row tied at the top
+            # m == 5: plain random row
+        return x
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["normal", "narrow", "wide", "adversarial"])
+@pytest.mark.parametrize("R,K", SHAPES)
+def test_fwd_matches_oracle(dev, oracle_mod, R, K, kind):
+    from lvmhelpers import _native
+    rng = np.random.default_rng(1000 * K + R)
+    x = _rows(rng, R, K, kind)
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    ent_ref = oracle_mod.entropy(p_ref)
+    xt = torch.from_numpy(x).to(dev)
+    for extra in (False, True):
+        p, supp, nnz, tau, ent = _native.sparsemax_fwd(xt, want_nnz=extra, want_tau=extra,
+                                                       want_entropy=extra)
+        p = p.cpu().numpy()
+        assert np.array_equal(p > 0, p_ref > 0), "support pattern differs"
+        assert np.array_equal(supp.cpu().numpy(), s_ref)
+        assert np.array_equal(p, p_ref), f"max |dp| = {np.abs(p - p_ref).max()}"
+        if extra:
+            assert np.array_equal(nnz.cpu().numpy(), nnz_ref)
+            assert np.array_equal(tau.cpu().numpy(), tau_ref)
+            np.testing.assert_allclose(ent.cpu().numpy(), ent_ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("R,K", SHAPES)
+def test_unaligned_rows_use_scalar_path(dev, oracle_mod, R, K):
+    """A view whose base pointer is not 16-byte aligned must take the scalar-load kernels."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    buf = torch.empty(R * K + 1, dtype=torch.float32, device=dev)
+    xt = buf[1:].view(R, K)
+    xt.copy_(torch.from_numpy(x))
+    assert xt.data_ptr() % 16 != 0
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    # _native.contiguous() keeps the view (it is contiguous), so the kernel sees the odd pointer
+    p, supp, _, _, _ = _native.sparsemax_fwd(xt)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    assert np.array_equal(supp.cpu().numpy(), s_ref)
+
+
+@pytest.mark.parametrize("kind", ["normal", "narrow", "adversarial"])
+@pytest.mark.parametrize("R,K", SHAPES)
+def test_bwd_matches_oracle(dev, oracle_mod, R, K, kind):
+    from lvmhelpers import _native
+    rng = np.random.default_rng(7 * K + R)
+    x = _rows(rng, R, K, kind)
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    dx = _native.sparsemax_bwd(torch.from_numpy(dy).to(dev), torch.from_numpy(p_ref).to(dev),
+                               torch.from_numpy(s_ref).to(dev)).cpu().numpy()
+    assert np.array_equal(dx != 0, dx_ref != 0) or np.array_equal((dx == 0) | (p_ref != 0), np.ones_like(dx, bool))
+    assert np.array_equal(dx[p_ref == 0], dx_ref[p_ref == 0])  # exact zeros off the support
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    assert np.all(np.abs(dx - dx_ref) <= 1e-6 * scale), np.abs(dx - dx_ref).max()
+
+
+def test_autograd_function(dev, oracle_mod):
+    from lvmhelpers import functional as F_
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((64, 256)).astype(np.float32)
+    w = rng.standard_normal((64, 256)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    p = F_.sparsemax(xt, dim=-1)
+    (p * torch.from_numpy(w).to(dev)).sum().backward()
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(w, p_ref, s_ref)
+    assert np.array_equal(p.detach().cpu().numpy(), p_ref)
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), dx_ref, rtol=0, atol=1e-6 * np.abs(w).max())
+    # dim != -1
+    xt2 = torch.from_numpy(x).to(dev)
+    p0 = F_.sparsemax(xt2, dim=0)
+    p0_ref, _, _, _ = oracle_mod.sparsemax_fwd(np.ascontiguousarray(x.T))
+    assert np.array_equal(p0.cpu().numpy(), p0_ref.T)
+
+
+def test_large_sizes_properties(dev):
+    """BASELINE sizes: size-independent properties (sum to one, shift invariance, threshold
+    consistency, idempotent support) instead of the oracle."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(1234)
+    for R, K in ((1 << 16, 256), (1 << 12, 4096), (256, 65536)):
+        x = torch.randn(R, K, device=dev, generator=g)
+        p, supp, nnz, tau, _ = _native.sparsemax_fwd(x, want_nnz=True, want_tau=True)
+        assert torch.all(p >= 0)
+        assert torch.all((p.double().sum(-1) - 1).abs() <= 1e-6 * max(1.0, K / 4096) + 2e-6)
+        z = x - x.max(dim=-1, keepdim=True)[0]
+        assert torch.equal(p > 0, z > tau.unsqueeze(-1))
+        assert torch.equal(nnz, (p > 0).sum(-1).to(torch.int32))
+        assert torch.equal(supp, nnz)
+        p2, supp2, _, _, _ = _native.sparsemax_fwd(x + 3.0)
+        assert torch.equal(supp2, supp)
+        assert torch.all((p2 - p).abs() <= 4e-6)
+        dy = torch.randn(R, K, device=dev, generator=g)
+        dx = _native.sparsemax_bwd(dy, p, supp)
+        assert torch.equal(dx != 0, (p != 0) & (dx != 0))
+        assert torch.all(dx.double().sum(-1).abs() <= 1e-4)
