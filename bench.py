@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the sparse-marginalization hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic logits: sparsemax forward +
+backward over a [rows, K] fp32 matrix resident in HBM (BASELINE.json configs[2], the synthetic
+sweep the metric is quoted on; default 1M rows x K=4096 per GPU, N(0,1) logits).  For N > 1 the
+driver launches this file with torch.distributed.run; rows are sharded per rank with no data-path
+collective (weak scaling: every rank owns `rows` rows), the timed region is bracketed by a barrier
++ synchronize on both sides and the maximum over ranks is reported.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel: algorithmic bytes per launch / mean launch time (HIP events on the
+                launch stream inside the timed region) against the 8 TB/s HBM peak
+  cpu_baseline  the CPU oracle (oracle/, plain C, 1 thread) timed on this host on a bounded sample
+  sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
+  sparsemap     batched active-set solver: samples/s and active-set iterations/s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sparse-marginalization-lvm_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=1 << 20, help="rows per GPU")
+    ap.add_argument("--K", type=int, default=4096)
+    ap.add_argument("--sigma", type=float, default=1.0, help="logits ~ N(0, sigma^2)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the K=256/65536 and SparseMAP extras")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
+    """Returns (wall seconds for `steps` fwd+bwd passes, mean fwd ms, mean bwd ms)."""
+    R, K = x.shape
+    p = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    supp = torch.empty(R, dtype=torch.int32, device=dev)
+    L = native.lib()
+    import ctypes
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def fwd():
+        rc = L.smlvm_sparsemax_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(p.data_ptr()),
+                                   ctypes.c_void_p(supp.data_ptr()), None, None, None,
+                                   ctypes.c_int64(R), ctypes.c_int32(K), st)
+        assert rc == 0, rc
+
+    def bwd():
+        rc = L.smlvm_sparsemax_bwd(ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(p.data_ptr()),
+                                   ctypes.c_void_p(supp.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
+                                   ctypes.c_int64(R), ctypes.c_int32(K), st)
+        assert rc == 0, rc
+
+    for _ in range(warmup):
+        fwd(); bwd()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record(); fwd(); ev[i][1].record(); bwd(); ev[i][2].record()
+    barrier(world)
+    wall = time.perf_counter() - t0
+    f_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+    b_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    mean_supp = float(supp.float().mean().item())
+    del p, dx
+    return wall, f_ms, b_ms, mean_supp
+
+
+def gen(R, K, sigma, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.empty(R, K, device=dev, dtype=torch.float32)
+    x.normal_(0.0, sigma, generator=g)
+    dy = torch.empty(R, K, device=dev, dtype=torch.float32)
+    dy.normal_(0.0, 1.0, generator=g)
+    return x, dy
+
+
+def cpu_baseline(K, sigma):
+    """The plain-C oracle (1 thread) on a bounded sample of the same workload, ~10 s."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(0)
+
+    def run(rows):
+        x = (sigma * rng.standard_normal((rows, K))).astype(np.float32)
+        dy = rng.standard_normal((rows, K)).astype(np.float32)
+        t0 = time.perf_counter()
+        p, s, _, _ = oracle.sparsemax_fwd(x)
+        oracle.sparsemax_bwd(dy, p, s)
+        return time.perf_counter() - t0
+
+    probe_rows = max(8, (1 << 22) // K)
+    t = run(probe_rows)
+    rows = int(max(probe_rows, min(10.0 / max(t / probe_rows, 1e-9), (1 << 28) // K)))
+    t = run(rows)
+    return {"value": rows / t, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{rows} rows x K={K} fp32 N(0,{sigma}^2), oracle/sparsemax_oracle.c fwd+bwd, "
+                      f"{t:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5):
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn(B, n, device=dev, generator=g) * sigma
+    init = torch.rand(B, 2 * n, dtype=torch.double,
+                      generator=torch.Generator().manual_seed(42)).to(dev)
+    out = native.sparsemap_fwd(x, init, budget, 300)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = native.sparsemap_fwd(x, init, budget, 300)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    dp = torch.randn(B, n + 1, device=dev, generator=g)
+    e0.record()
+    for _ in range(reps):
+        native.sparsemap_bwd(dp, out["aset_bits"], out["alen"], out["inv_a"], n)
+    e1.record()
+    torch.cuda.synchronize()
+    bms = e0.elapsed_time(e1) / reps
+    iters = float(out["iters"].double().sum().item())
+    return {"B": B, "bits": n, "budget": budget, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
+            "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
+            "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
+            "converged_frac": float((out["status"] != 1).float().mean().item())}
+
+
+def main():
+    a = parse()
+    world, rank, local = dist_setup(a.gpus)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    from lvmhelpers import _native as native
+    native.lib()
+
+    x, dy = gen(a.rows, a.K, a.sigma, dev, 1234 + rank)
+    wall, f_ms, b_ms, mean_supp = timed_sparsemax(native, x, dy, a.steps, a.warmup, world, dev)
+    wall = max_over_ranks(wall, world, dev)
+    del x, dy
+    torch.cuda.empty_cache()
+
+    rows_total = a.rows * world * a.steps
+    fwd_bytes = 8.0 * a.K * a.rows
+    bwd_bytes = 12.0 * a.K * a.rows
+    kern = {
+        "sparsemax_fwd": {"ms": f_ms, "algorithmic_bytes": fwd_bytes,
+                          "GBps": fwd_bytes / (f_ms * 1e-3) / 1e9},
+        "sparsemax_bwd": {"ms": b_ms, "algorithmic_bytes": bwd_bytes,
+                          "GBps": bwd_bytes / (b_ms * 1e-3) / 1e9},
+    }
+    dom = "sparsemax_fwd" if f_ms >= b_ms else "sparsemax_bwd"
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"{dom}_K{a.K}_R{a.rows}")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "sparsemax_fwd_bwd_rows_per_sec",
+        "value": rows_total / wall,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic sparsemax fwd+bwd sweep, {a.rows} rows/GPU x K={a.K} fp32, "
+                               f"logits N(0,{a.sigma}^2) (BASELINE.json configs[2])",
+                   "rows_per_gpu": a.rows, "K": a.K, "mean_support": mean_supp,
+                   "parallelism": f"rows sharded over {world} GPU(s), no collective"},
+        "fwd_bwd_GBps_per_gpu": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9,
+        "fwd_bwd_frac_of_hbm_peak": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"],
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
+                     "traffic": traffic},
+        "kernels": kern,
+    }
+
+    if rank == 0 and world == 1 and not a.no_sweep:
+        sweep = {}
+        for K, R, chunks in ((256, 1 << 20, 1), (65536, 1 << 15, 32)):
+            xs, dys = gen(R, K, a.sigma, dev, 99)
+            w, fm, bm, ms_ = timed_sparsemax(native, xs, dys, max(3, a.steps // 4), 2, 1, dev)
+            del xs, dys
+            torch.cuda.empty_cache()
+            gb = 20.0 * K * R / ((fm + bm) * 1e-3) / 1e9
+            sweep[f"K{K}"] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "fwd_ms": fm,
+                              "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
+                              "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
+        out["sweep"] = sweep
+        out["sparsemap"] = [sparsemap_bench(native, dev, 64, 32, 0, 1.0),
+                            sparsemap_bench(native, dev, 64, 32, 16, 1.0),
+                            sparsemap_bench(native, dev, 1024, 128, 0, 1.0),
+                            sparsemap_bench(native, dev, 1024, 128, 64, 1.0),
+                            sparsemap_bench(native, dev, 1024, 128, 0, 3.0)]
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
