@@ -1,0 +1,116 @@
+"""CPU: pins the active-set SparseMAP oracle (oracle/sparsemap_oracle.c) with the mathematical
+invariants of SURVEY.md 8(c) (the reference's solver, lpsmap, is absent: parity unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+
+def _problem(B, n, sigma, seed):
+    rng = np.random.default_rng(seed)
+    x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+    init = torch.rand(B, 2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(42)).numpy()
+    return x, init
+
+
+def _marginals(o, n):
+    bits = oracle.unpack_bits(o["aset_bits"], n).astype(np.float64)
+    return np.einsum("bc,bcn->bn", o["p64"], bits), bits
+
+
+def _budget_projection(x, budget):
+    """Projection of (x+1)/2 onto {0 <= mu <= 1, sum mu <= budget} by bisection on the multiplier."""
+    a = (x.astype(np.float64) + 1) / 2
+    mu = np.clip(a, 0, 1)
+    out = mu.copy()
+    for b in range(x.shape[0]):
+        if mu[b].sum() <= budget:
+            continue
+        lo, hi = 0.0, a[b].max()
+        for _ in range(100):
+            mid = (lo + hi) / 2
+            if np.clip(a[b] - mid, 0, 1).sum() > budget:
+                lo = mid
+            else:
+                hi = mid
+        out[b] = np.clip(a[b] - hi, 0, 1)
+    return out
+
+
+@pytest.mark.parametrize("n,sigma,use_init", [(32, 1.0, True), (32, 1.0, False), (32, 3.0, True),
+                                              (5, 1.0, True), (1, 1.0, False), (64, 2.0, True)])
+def test_bernoulli_invariants(n, sigma, use_init):
+    x, init = _problem(48, n, sigma, n)
+    o = oracle.sparsemap_fwd(x, init if use_init else None, 0, 300)
+    ok = o["status"] == 0
+    assert ok.mean() > 0.95
+    mu, bits = _marginals(o, n)
+    assert np.abs(mu - np.clip((x.astype(np.float64) + 1) / 2, 0, 1))[ok].max() < 1e-6      # (i)
+    assert np.abs(o["p64"].sum(-1) - 1)[ok].max() < 1e-9                                     # (ii)
+    assert o["p64"][ok].min() >= -1e-12
+    for b in np.nonzero(ok)[0]:
+        m = o["alen"][b]
+        cfgs = {tuple(c) for c in bits[b, :m]}
+        assert len(cfgs) == m                                                               # (iv) distinct
+        M = np.concatenate([bits[b, :m], 1 - bits[b, :m]], 1)
+        A = np.zeros((m + 1, m + 1)); A[0, 1:] = 1; A[1:, 0] = 1; A[1:, 1:] = M @ M.T
+        assert np.abs(o["invA"][b, :m + 1, :m + 1] @ A - np.eye(m + 1)).max() < 1e-6        # (iv) invertible
+        eta = np.concatenate([x[b].astype(np.float64), np.zeros(n)])
+        resid = eta - M.T @ o["p64"][b, :m]
+        tau = (M @ resid).mean() if m else 0
+        assert np.maximum(resid[:n], resid[n:]).sum() <= tau + 1e-6                         # (iii) KKT
+
+
+@pytest.mark.parametrize("n,budget", [(32, 16), (32, 3), (20, 1), (64, 32)])
+def test_budget_marginals(n, budget):
+    x, init = _problem(32, n, 1.0, n + budget)
+    o = oracle.sparsemap_fwd(x, init, budget, 300)
+    ok = o["status"] == 0
+    assert ok.mean() > 0.9
+    mu, bits = _marginals(o, n)
+    assert np.all(bits.sum(-1)[o["p64"] > 0] <= budget)
+    assert np.abs(mu - _budget_projection(x, budget))[ok].max() < 1e-5
+
+
+def test_vertex_solution_without_init():                                                    # (vi)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((16, 24)).astype(np.float32)
+    x = np.sign(x) * (1 + np.abs(x))
+    o = oracle.sparsemap_fwd(x, None, 0, 300)
+    assert np.all(o["alen"] == 1) and np.all(o["p"][:, 0] == 1)
+    assert np.array_equal(oracle.unpack_bits(o["aset_bits"], 24)[:, 0], (x > 0).astype(np.float32))
+
+
+def test_jacobian_vector_product():                                                         # (v)
+    n = 16
+    x, init = _problem(12, n, 1.0, 3)
+    o = oracle.sparsemap_fwd(x, init, 0, 300)
+    rng = np.random.default_rng(1)
+    dp = rng.standard_normal((12, n + 1)).astype(np.float32)
+    d = oracle.sparsemap_bwd(dp, o["aset_bits"], o["alen"], o["invA"], n)
+    bits = oracle.unpack_bits(o["aset_bits"], n).astype(np.float64)
+    for b in range(12):
+        m = o["alen"][b]
+        M = np.concatenate([bits[b, :m], 1 - bits[b, :m]], 1).T          # [2n, m]
+        A = np.zeros((m + 1, m + 1)); A[0, 1:] = 1; A[1:, 0] = 1; A[1:, 1:] = M.T @ M
+        S = np.linalg.inv(A)[1:, 1:]
+        ref = (M @ (S @ dp[b, :m].astype(np.float64)))[:n]
+        assert np.allclose(d[b], ref, rtol=1e-5, atol=1e-6)
+        # finite differences of p on the fixed active set: p(eta) = S M^T eta + const
+        h = 1e-4
+        j = b % n
+        e = np.zeros(2 * n); e[j] = h
+        dpdeta = (S @ (M.T @ e)) / h
+        assert abs(dpdeta @ dp[b, :m] - d[b, j]) < 1e-4
+
+
+def test_init_stream_one_draw_equals_per_sample_draws():
+    """torch.rand(B, 2n) consumes the CPU generator exactly like B draws of torch.rand(2n)
+    (what lvmhelpers/sparsemap.py:26 does per sample)."""
+    for n in (32, 128):
+        torch.manual_seed(42)
+        one = torch.rand(7, 2 * n, dtype=torch.double)
+        torch.manual_seed(42)
+        many = torch.stack([torch.rand(2 * n, dtype=torch.double) for _ in range(7)])
+        assert torch.equal(one, many)
