@@ -203,17 +203,12 @@ __device__ __forceinline__ Edge edge_pass(const float (&z)[E], float lo, Red& re
     return r;
 }
 
-// z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
+// Threshold search on max-shifted values v[] (padding = -inf; every element that can be in the
+// support, i.e. > -1, must be present): Michelot iteration, then the exact edge.  Returns the
+// oracle's support size s and the fp64 sum S of its s largest elements.
 template <int E, class Red>
-__device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, int& supp, float& tau_out)
+__device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int& s_out, double& S_out)
 {
-    float mx = z[0];
-#pragma unroll
-    for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
-    mx = red.max(mx);
-#pragma unroll
-    for (int e = 0; e < E; ++e) z[e] -= mx;
-
     // --- Michelot iteration from the lower bound tau >= -1 (z_max = 0 after the shift).
     float tau = -1.0f;
     int cnt_prev = 0x7fffffff;
@@ -284,6 +279,119 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, int& supp
         for (int e = 0; e < E; ++e) up = (z[e] > lo) ? fminf(up, z[e]) : up;
         lo = red.min(up);
     }
+    s_out = s_final;
+    S_out = S_final;
+}
+
+// ------------------------------------------------------------------------------- candidates
+// Only elements within 1 of the row maximum can be in the support (tau >= max - 1).  With ML-like
+// logits that is a few dozen of K, so the threshold search runs on a compacted candidate list
+// (through LDS, <= kCandPerLane per lane) instead of on all E registers; rows with more candidates
+// than the list holds (near-uniform rows) take the full-width search.
+constexpr int kCandPerLane = 4;
+constexpr int kCandCap = 64 * kCandPerLane;  // candidates per row on the fast path
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// Appends this wave's elements > thr to list[0..cap) in lane order per register; returns how many
+// there are (may exceed cap: then the list is incomplete and the caller must not use it).
+template <int E>
+__device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr, float* list,
+                                                  int cap)
+{
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = z[e] > thr;
+        const unsigned long long m = __ballot(in);
+        if (m != 0ull) {  // wave-uniform
+            const int off = base + lanes_below(m);
+            if (in && off < cap) list[off] = z[e];
+            base += __popcll(m);
+        }
+    }
+    return base;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
+// NW = waves holding the row (1: a lane group of one wave; then G < 64 skips the candidate path).
+// cand: LDS, NW == 1: kCandCap floats private to this wave; NW > 1: NW*64 floats + NW ints.
+template <int E, int NW, bool CAND, class Red>
+__device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
+                                              float& tau_out)
+{
+    float mx = z[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    mx = red.max(mx);
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] -= mx;
+
+    int s_final = 1;
+    double S_final = 0.0;
+    bool fast = false;
+    if constexpr (CAND) {
+        const int lane = threadIdx.x & 63;
+        float c[kCandPerLane];
+        if constexpr (NW == 1) {
+            const int n_c = compact_candidates(z, -1.0f, cand, kCandCap);
+            fast = n_c <= kCandCap;
+            if (fast) {
+                wave_lds_sync();
+#pragma unroll
+                for (int q = 0; q < kCandPerLane; ++q)
+                    c[q] = (lane + 64 * q < n_c) ? cand[lane + 64 * q] : -INFINITY;
+                wave_lds_sync();
+            }
+        } else {
+            const int wave = threadIdx.x >> 6;
+            int* cnt = reinterpret_cast<int*>(cand + NW * 64);
+            const int n_w = compact_candidates(z, -1.0f, cand + wave * 64, 64);
+            if (lane == 0) cnt[wave] = n_w;
+            __syncthreads();
+            int total = 0, worst = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int k = cnt[w];
+                total += k;
+                worst = k > worst ? k : worst;
+            }
+            fast = worst <= 64 && total <= kCandCap;
+            if (fast) {
+#pragma unroll
+                for (int q = 0; q < kCandPerLane; ++q) {
+                    const int idx = lane + 64 * q;
+                    float v = -INFINITY;
+                    int pre = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int k = cnt[w];
+                        if (idx >= pre && idx < pre + k) v = cand[w * 64 + (idx - pre)];
+                        pre += k;
+                    }
+                    c[q] = v;
+                }
+            }
+            __syncthreads();  // the lists are rewritten by the next row
+        }
+        if (fast) {
+            WaveRed<64> wred;  // every wave solves the same small problem: no barriers
+            solve_core(c, wred, s_final, S_final);
+        }
+    }
+    if (!fast) solve_core(z, red, s_final, S_final);
 
     float c_s = (float)S_final - 1.0f;
     float tau_f = c_s / (float)s_final;
@@ -316,6 +424,20 @@ __device__ __forceinline__ void row_epilogue(const float (&p)[E], Red& red, bool
     }
 }
 
+// Streaming (non-temporal) 16-byte accesses: every element is read once and written once, so
+// the lines should not linger in L2 / Infinity Cache (+8 % on a plain tile copy on MI355X).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4* p, float4 v)
+{
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+}
+
 // ------------------------------------------------------------------------------- row <-> regs
 // Lane `gl` of a group of GT lanes owns, for chunk i, the float4 with index i*GT + gl (VEC) or
 // the element i*GT + gl (scalar): every load/store instruction covers consecutive addresses.
@@ -331,7 +453,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, i
         for (int i = 0; i < E / 4; ++i) {
             int f = i * GT + gl;
             float4 v = make_float4(pad, pad, pad, pad);
-            if (FULL || f < K4) v = r4[f];
+            if (FULL || f < K4) v = nt_load4(r4 + f);
             z[4 * i + 0] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
         }
     } else {
@@ -353,7 +475,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
 #pragma unroll
         for (int i = 0; i < E / 4; ++i) {
             int f = i * GT + gl;
-            if (FULL || f < K4) r4[f] = make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]);
+            if (FULL || f < K4) nt_store4(r4 + f, make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]));
         }
     } else {
 #pragma unroll
@@ -382,12 +504,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
+    constexpr bool CAND = (G == 64);
+    __shared__ float cand[CAND ? kWavesPerBlock * kCandCap : 1];
     float z[E];
     load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
     WaveRed<G> red;
     int s, n = 0;
     float t, h = 0.0f;
-    sparsemax_row(z, red, s, t);
+    sparsemax_row<E, 1, CAND>(z, red, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0), s, t);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
@@ -408,13 +532,14 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
     int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    __shared__ float cand[NW * 64 + NW];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
         float z[E];
         load_row<E, VEC, FULL>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
         int s, n = 0;
         float t, h = 0.0f;
-        sparsemax_row(z, red, s, t);
+        sparsemax_row<E, NW, true>(z, red, cand, s, t);
         if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
         store_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, z);
         if (threadIdx.x == 0) {

@@ -1,0 +1,187 @@
+// HBM ceiling probes for the access shapes of the sparsemax kernels (float4 per lane, streaming).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/membench.hip -o tools/membench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) o[i] = a[i];
+}
+// each block handles a contiguous tile of U float4 per thread (like one row per wave)
+template <int U>
+__global__ __launch_bounds__(256) void k_copy_tile(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    const float4* src = a + wave * (64 * U);
+    float4* dst = o + wave * (64 * U);
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u * 64 + lane] = v[u];
+}
+template <int U>
+__global__ __launch_bounds__(256) void k_2r1w_tile(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o, size_t n)
+{
+    size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    const float4* s1 = a + wave * (64 * U);
+    const float4* s2 = b + wave * (64 * U);
+    float4* dst = o + wave * (64 * U);
+    float4 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { v[u] = s1[u * 64 + lane]; w[u] = s2[u * 64 + lane]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[u * 64 + lane] = make_float4(v[u].x + w[u].x, v[u].y + w[u].y, v[u].z + w[u].z, v[u].w + w[u].w);
+}
+__global__ __launch_bounds__(256) void k_read(const float4* __restrict__ a, float* __restrict__ o, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * 256;
+    float s = 0;
+    for (; i < n; i += stride) { float4 v = a[i]; s += v.x + v.y + v.z + v.w; }
+    if (s == 123.456f) o[0] = s;
+}
+__global__ __launch_bounds__(256) void k_write(float4* __restrict__ o, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) o[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+template <int U, bool NTL, bool NTS, int BS>
+__global__ __launch_bounds__(BS) void k_copy_tile_nt(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    size_t wave = ((size_t)blockIdx.x * BS + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    const float4* src = a + wave * (64 * U);
+    float4* dst = o + wave * (64 * U);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    f4* d4 = reinterpret_cast<f4*>(dst);
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NTL) v[u] = __builtin_nontemporal_load(s4 + u * 64 + lane); else v[u] = s4[u * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NTS) __builtin_nontemporal_store(v[u], d4 + u * 64 + lane); else d4[u * 64 + lane] = v[u];
+    }
+}
+
+// block tile: the BS threads of a block jointly own BS*U consecutive float4; instruction u covers
+// BS*16 contiguous bytes
+template <int U, int BS, bool NT>
+__global__ __launch_bounds__(BS) void k_copy_btile(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(a) + (size_t)blockIdx.x * (BS * U);
+    f4* d4 = reinterpret_cast<f4*>(o) + (size_t)blockIdx.x * (BS * U);
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NT) v[u] = __builtin_nontemporal_load(s4 + u * BS + threadIdx.x); else v[u] = s4[u * BS + threadIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NT) __builtin_nontemporal_store(v[u], d4 + u * BS + threadIdx.x); else d4[u * BS + threadIdx.x] = v[u];
+    }
+}
+template <int U, int BS, bool NT>
+__global__ __launch_bounds__(BS) void k_2r1w_btile(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o, size_t n)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(a) + (size_t)blockIdx.x * (BS * U);
+    const f4* t4 = reinterpret_cast<const f4*>(b) + (size_t)blockIdx.x * (BS * U);
+    f4* d4 = reinterpret_cast<f4*>(o) + (size_t)blockIdx.x * (BS * U);
+    f4 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NT) { v[u] = __builtin_nontemporal_load(s4 + u * BS + threadIdx.x); w[u] = __builtin_nontemporal_load(t4 + u * BS + threadIdx.x); }
+        else { v[u] = s4[u * BS + threadIdx.x]; w[u] = t4[u * BS + threadIdx.x]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (NT) __builtin_nontemporal_store(v[u] + w[u], d4 + u * BS + threadIdx.x); else d4[u * BS + threadIdx.x] = v[u] + w[u];
+    }
+}
+
+template <class F>
+static double timeit(F f, int reps = 10)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps * 1e-3;
+}
+
+int main(int argc, char** argv)
+{
+    size_t bytes = (size_t)16 << 30;  // per tensor
+    if (argc > 1) bytes = (size_t)atof(argv[1]) * (1ull << 30);
+    size_t n = bytes / 16;
+    float4 *a, *b, *o;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
+    double t;
+    for (int g : {2048, 8192, 65536}) {
+        t = timeit([&] { k_copy<<<g, 256>>>(a, o, n); });
+        printf("copy grid-stride grid=%d: %.2f TB/s\n", g, 2.0 * bytes / t / 1e12);
+    }
+    t = timeit([&] { k_copy_tile<4><<<(unsigned)(n / (4 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=4  (1 KB/lane-group of 64: K=1024 row per wave): %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile<16><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=16 (K=4096 row per wave): %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_2r1w_tile<4><<<(unsigned)(n / (4 * 256)), 256>>>(a, b, o, n); });
+    printf("2R1W tile U=4 : %.2f TB/s\n", 3.0 * bytes / t / 1e12);
+    t = timeit([&] { k_2r1w_tile<16><<<(unsigned)(n / (16 * 256)), 256>>>(a, b, o, n); });
+    printf("2R1W tile U=16: %.2f TB/s\n", 3.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<16, true, false, 256><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=16 nt-load : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<16, false, true, 256><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=16 nt-store: %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<16, true, true, 256><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=16 nt-both : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<4, true, true, 256><<<(unsigned)(n / (4 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=4  nt-both : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<4, true, true, 1024><<<(unsigned)(n / (4 * 1024)), 1024>>>(a, o, n); });
+    printf("copy tile U=4  nt-both BS=1024: %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<1, true, true, 256><<<(unsigned)(n / (1 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=1  nt-both : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<1, false, false, 256><<<(unsigned)(n / (1 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=1  plain   : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    t = timeit([&] { k_copy_tile_nt<2, false, false, 256><<<(unsigned)(n / (2 * 256)), 256>>>(a, o, n); });
+    printf("copy tile U=2  plain   : %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+    for (int ldsk : {0, 20, 26, 40, 80}) {   // KB of dynamic LDS per block -> caps blocks per CU at 160/ldsk
+        t = timeit([&] { k_copy_tile_nt<16, true, true, 256><<<(unsigned)(n / (16 * 256)), 256, ldsk * 1024>>>(a, o, n); });
+        printf("copy tile U=16 nt-both BS=256 lds=%dKB: %.2f TB/s\n", ldsk, 2.0 * bytes / t / 1e12);
+        t = timeit([&] { k_copy_tile_nt<16, true, true, 64><<<(unsigned)(n / (16 * 64)), 64, ldsk * 256>>>(a, o, n); });
+        printf("copy tile U=16 nt-both BS=64  lds=%dKB: %.2f TB/s\n", ldsk / 4, 2.0 * bytes / t / 1e12);
+        t = timeit([&] { k_copy_tile_nt<4, true, true, 256><<<(unsigned)(n / (4 * 256)), 256, ldsk * 1024>>>(a, o, n); });
+        printf("copy tile U=4  nt-both BS=256 lds=%dKB: %.2f TB/s\n", ldsk, 2.0 * bytes / t / 1e12);
+    }
+#define BT(U, BS, NT) t = timeit([&] { k_copy_btile<U, BS, NT><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(a, o, n); }); \
+    printf("copy block-tile U=%d BS=%d nt=%d: %.2f TB/s\n", U, BS, (int)NT, 2.0 * bytes / t / 1e12);
+    BT(4, 256, false) BT(4, 256, true) BT(16, 256, true) BT(4, 1024, true) BT(16, 1024, true) BT(8, 512, true) BT(2, 256, true) BT(1, 256, true) BT(1, 1024, true) BT(1, 64, true) BT(4, 64, true)
+#define BT3(U, BS, NT) t = timeit([&] { k_2r1w_btile<U, BS, NT><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(a, b, o, n); }); \
+    printf("2R1W block-tile U=%d BS=%d nt=%d: %.2f TB/s\n", U, BS, (int)NT, 3.0 * bytes / t / 1e12);
+    BT3(4, 256, false) BT3(4, 256, true) BT3(16, 64, true) BT3(16, 256, true) BT3(1, 256, true) BT3(4, 64, true) BT3(16, 1024, true)
+    t = timeit([&] { k_read<<<8192, 256>>>(a, (float*)o, n); });
+    printf("read only : %.2f TB/s\n", 1.0 * bytes / t / 1e12);
+    t = timeit([&] { k_write<<<8192, 256>>>(o, n); });
+    printf("write only: %.2f TB/s\n", 1.0 * bytes / t / 1e12);
+    return 0;
+}
