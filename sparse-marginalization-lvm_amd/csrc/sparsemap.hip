@@ -64,6 +64,7 @@ __device__ __forceinline__ double bcast_f64(double v, int lane)
 __device__ __forceinline__ double serial_sum(const double* a, int len)
 {
     double v = 0.0;
+#pragma unroll 16
     for (int k = 0; k < len; ++k) v += a[k];
     return v;
 }
@@ -119,8 +120,13 @@ __device__ double maximize(const SmLayout& L, char* sm, int budget, int lane)
         }
     }
     wsync();
-    value = serial_sum(off, n);
-    double sum = serial_sum(term, n);  // adding 0.0 for the inactive ones changes nothing
+    value = 0.0;
+    double sum = 0.0;  // adding 0.0 for the inactive ones changes nothing
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) {  // two independent serial chains, interleaved
+        value += off[k];
+        sum += term[k];
+    }
     if (num_active > budget) {
         // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
         int cnt_sel = 0;
@@ -130,6 +136,7 @@ __device__ double maximize(const SmLayout& L, char* sm, int budget, int lane)
             if (k < n) {
                 const double ek = e[k];
                 int rank = 0;
+#pragma unroll 8
                 for (int j = 0; j < n; ++j) {
                     const double ej = e[j];
                     rank += ((-ej < -ek) || (!(-ek < -ej) && j < k)) ? 1 : 0;
@@ -156,7 +163,12 @@ __device__ __forceinline__ double evaluate(const SmLayout& L, char* sm, const ui
 {
     const double* eta = (const double*)(sm + L.eta);
     double v = 0.0;
-    for (int k = 0; k < L.n; ++k) v += ((c[k >> 5] >> (k & 31)) & 1u) ? eta[k] : 0.0;
+    for (int w = 0; w < L.W; ++w) {
+        const uint32_t bits = c[w];
+        const int k0 = w * 32, kn = (L.n - k0 < 32) ? (L.n - k0) : 32;
+#pragma unroll 8
+        for (int b = 0; b < kn; ++b) v += ((bits >> b) & 1u) ? eta[k0 + b] : 0.0;
+    }
     return v;
 }
 
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     wsync();
     {
         const double v = evaluate(L, sm, cfg);
-        if (lane == 0) bsc[0] = v;
+        if (lane == 0) { bsc[0] = 1.0; bsc[1] = v; }
     }
     int m = 1;
     wsync();
@@ -219,7 +231,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             double t0 = 0.0;
             for (int c = lane; c <= m; c += 64) {
                 double acc = 0.0;
-                for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * (j == 0 ? 1.0 : bsc[j - 1]);
+#pragma unroll 8
+                for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bsc[j];
                 if (c == 0) t0 = acc; else z[c - 1] = acc;
             }
             tau = bcast_f64(t0, 0);
@@ -229,9 +242,15 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         if (same) {
             for (int k = lane; k < n; k += 64) {
                 double mon = 0.0, moff = 0.0;
+                const uint32_t* cw = cfg + (k >> 5);
+                const int sh = k & 31;
+#pragma unroll 8
                 for (int i = 0; i < m; ++i) {
                     const double zi = z[i];
-                    if ((cfg[i * W + (k >> 5)] >> (k & 31)) & 1u) mon += zi; else moff += zi;
+                    const bool bit = (cw[i * W] >> sh) & 1u;
+                    // x + 0.0 == x bit for bit (the sums never hold -0.0): add to both chains
+                    mon += bit ? zi : 0.0;
+                    moff += bit ? 0.0 : zi;
                 }
                 on[k] = eta[k] - mon;
                 off[k] = 0.0 - moff;
@@ -266,21 +285,26 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             wsync();
             for (int j = lane; j <= m; j += 64) {
                 double acc = 0.0;
+#pragma unroll 8
                 for (int i = 0; i <= m; ++i) {
                     const double ri = r[i];
-                    if (ri == 0.0) continue;
-                    acc += A[i * ld + j] * ri;
+                    const double t = acc + A[i * ld + j] * ri;
+                    acc = (ri == 0.0) ? acc : t;  // terms with r_i == 0 are skipped (oracle C4)
                 }
                 d[j] = acc;
             }
             wsync();
             double sden = (double)n;
+#pragma unroll 8
             for (int j = 0; j <= m; ++j) sden -= r[j] * d[j];
             if (sden <= 1e-9 && sden >= -1e-9) { st = SM_SINGULAR; break; }
             const double invs = 1.0 / sden;
-            for (int i = 0; i <= m; ++i) {
-                const double di = d[i];
-                for (int j = lane; j <= m; j += 64) A[i * ld + j] = A[i * ld + j] + invs * di * d[j];
+            for (int j = lane; j <= m; j += 64) {  // lane owns column j; d[] is read-only here
+                const double dj = d[j];
+                double* __restrict__ col = A + j;          // A and d never overlap
+                const double* __restrict__ dd = d;
+#pragma unroll 8
+                for (int i = 0; i <= m; ++i) col[i * ld] = col[i * ld] + invs * dd[i] * dj;
             }
             for (int i = lane; i <= m; i += 64) {
                 const double v = -invs * d[i];
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             wsync();
             {
                 const double v = evaluate(L, sm, cfg + m * W);
-                if (lane == 0) bsc[m] = v;
+                if (lane == 0) bsc[m + 1] = v;
             }
             ++m;
             changed = true;
@@ -351,13 +375,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                         const int j = j0 + lane;
                         double v = 0.0;
                         const bool ok = (j <= m) && (j != ri);
+                        // one wave: LDS executes its instructions in order, so every lane's read of
+                        // this chunk precedes every lane's write below
                         if (ok) v = A[i * ld + j];
-                        wsync();
                         if (ok) {
                             const int l = j - (j > ri ? 1 : 0);
                             A[kk * ld + l] = v - invs * dk * d[l];
                         }
-                        wsync();
                     }
                 }
                 // erase entry `blocking` from cfg / z / dist / bsc (chunks ascending: read, then write)
@@ -367,13 +391,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                     double zv = 0.0, dv = 0.0, bv = 0.0;
                     uint32_t cw[4] = {0u, 0u, 0u, 0u};
                     if (ok) {
-                        zv = z[i + 1]; dv = dist[i + 1]; bv = bsc[i + 1];
+                        zv = z[i + 1]; dv = dist[i + 1]; bv = bsc[i + 2];
 #pragma unroll
                         for (int w = 0; w < 4; ++w) if (w < W) cw[w] = cfg[(i + 1) * W + w];
                     }
                     wsync();
                     if (ok) {
-                        z[i] = zv; dist[i] = dv; bsc[i] = bv;
+                        z[i] = zv; dist[i] = dv; bsc[i + 1] = bv;
 #pragma unroll
                         for (int w = 0; w < 4; ++w) if (w < W) cfg[i * W + w] = cw[w];
                     }
