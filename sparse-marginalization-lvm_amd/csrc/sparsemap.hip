@@ -51,6 +51,21 @@ struct SmLayout {
 
 __device__ __forceinline__ void wsync() { __syncthreads(); }  // single-wave workgroup
 
+// Diagnostic build only (tools/sm_prof.hip defines SMLVM_SM_PROF): cycles per solver phase.
+#ifdef SMLVM_SM_PROF
+__device__ unsigned long long g_prof[16];
+#define SM_T(k)                                                                   \
+    do {                                                                          \
+        long long now_ = clock64();                                               \
+        if (threadIdx.x == 0) atomicAdd(&g_prof[k], (unsigned long long)(now_ - t_last_)); \
+        t_last_ = now_;                                                           \
+    } while (0)
+#define SM_T0() long long t_last_ = clock64()
+#else
+#define SM_T(k) do { } while (0)
+#define SM_T0() do { } while (0)
+#endif
+
 __device__ __forceinline__ double bcast_f64(double v, int lane)
 {
     long long b = __builtin_bit_cast(long long, v);
@@ -221,6 +236,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     int m = 1;
     wsync();
 
+    SM_T0();
     bool changed = true;
     int st = SM_MAXITER, it;
     double tau = 0.0;
@@ -238,6 +254,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             tau = bcast_f64(t0, 0);
             same = false;
             wsync();
+            SM_T(0);
         }
         if (same) {
             for (int k = lane; k < n; k += 64) {
@@ -256,7 +273,9 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 off[k] = 0.0 - moff;
             }
             wsync();
+            SM_T(1);
             const double value = maximize(L, sm, budget, lane);
+            SM_T(2);
             if (value <= tau + 1e-9) { st = SM_CONVERGED; break; }
             bool dup = false;
             for (int i = lane; i < m; i += 64) {
@@ -283,6 +302,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 r[i] = ri;
             }
             wsync();
+            SM_T(3);
             for (int j = lane; j <= m; j += 64) {
                 double acc = 0.0;
 #pragma unroll 8
@@ -294,11 +314,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 d[j] = acc;
             }
             wsync();
+            SM_T(4);
             double sden = (double)n;
 #pragma unroll 8
             for (int j = 0; j <= m; ++j) sden -= r[j] * d[j];
             if (sden <= 1e-9 && sden >= -1e-9) { st = SM_SINGULAR; break; }
             const double invs = 1.0 / sden;
+            SM_T(5);
             for (int j = lane; j <= m; j += 64) {  // lane owns column j; d[] is read-only here
                 const double dj = d[j];
                 double* __restrict__ col = A + j;          // A and d never overlap
@@ -314,6 +336,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             if (lane == 0) A[(m + 1) * ld + (m + 1)] = invs;
             for (int w = lane; w < W; w += 64) cfg[m * W + w] = newc[w];
             wsync();
+            SM_T(6);
             {
                 const double v = evaluate(L, sm, cfg + m * W);
                 if (lane == 0) bsc[m + 1] = v;
@@ -321,6 +344,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             ++m;
             changed = true;
             wsync();
+            SM_T(7);
         } else {
             // blocking constraints: argmin of dist/(dist - z) over {z < dist}, first index on ties
             double best = INFINITY;
@@ -338,6 +362,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 for (int i = lane; i < m; i += 64) dist[i] = z[i];
                 changed = false;
                 wsync();
+                SM_T(8);
             } else {
                 // wave argmin (value, then index)
 #pragma unroll
@@ -406,6 +431,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 --m;
                 changed = true;
                 wsync();
+                SM_T(9);
             }
         }
     }
