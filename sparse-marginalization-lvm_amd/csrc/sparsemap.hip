@@ -10,12 +10,20 @@
 // active set -- which is path dependent -- comes out identical: every fp64 inner product that
 // feeds a decision is accumulated serially in the oracle's order by ONE lane (lane c owns output
 // c; sums that produce a single scalar are accumulated redundantly by all lanes from LDS
-// broadcasts), there is no FMA contraction (this file is built with -ffp-contract=off) and
+// broadcasts), there is no FMA contraction (this file is built with -ffp-contract=off; the two
+// explicit fma() calls multiply by exactly 1.0 or 0.0, which makes them plain additions) and
 // division is IEEE.  Parallelism comes from the 64 lanes owning different outputs, from the
 // rank-one updates of the cached inverse KKT matrix, and from one workgroup per sample.
 //
-// LDS per sample (n = bits, cap = n+1 configurations, ld = n+2): the (ld x ld) fp64 inverse KKT
-// matrix dominates: 9.2 KB at n = 32, 135 KB at n = 128 (one sample per CU at a time).
+// The solver is latency bound (a wave walks dependent fp64 additions), so the loops are written
+// as 8-step batches whose LDS operands are fetched one batch ahead (ping-pong registers): a step
+// then costs about one dependent v_add_f64 instead of one LDS round trip.  Every vector that a
+// serial loop reads is kept zero-padded to a multiple of 8 (x + 0.0 == x bit for bit; the sums
+// never hold -0.0), and rows of the inverse beyond the live block always hold finite numbers
+// (zero-initialised, later only stale values), so padded steps are exact no-ops.
+//
+// LDS per sample (template LD = storage order of the inverse KKT matrix >= n+2): 8.LD^2 bytes
+// dominate: 9.5 KB at n = 32, 141 KB at n = 128 (one sample per CU at a time).
 #include "common.hpp"
 
 #include <math.h>
@@ -24,29 +32,33 @@ namespace smlvm {
 
 enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3 };
 
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+constexpr int round8(int v) { return (v + 7) & ~7; }
+
+// LD: rows/columns of storage for the inverse KKT matrix (indices 0..m, m <= LD-1).
+// WT: 32-bit words per stored configuration (>= ceil(n/32)).  NK: 64-lane chunks over variables.
+template <int LD, int WT, int NK>
 struct SmLayout {
-    int n, cap, ld, W;
-    // offsets in bytes
-    size_t A, z, dist, bsc, d, r, on, off, term, e, eta, sorted, cfg, newc, total;
-    __host__ __device__ SmLayout(int n_) : n(n_), cap(n_ + 1), ld(n_ + 2), W((n_ + 31) / 32)
-    {
-        size_t o = 0;
-        A = o;      o += sizeof(double) * (size_t)ld * ld;
-        z = o;      o += sizeof(double) * ld;
-        dist = o;   o += sizeof(double) * ld;
-        bsc = o;    o += sizeof(double) * ld;
-        d = o;      o += sizeof(double) * ld;
-        r = o;      o += sizeof(double) * ld;
-        on = o;     o += sizeof(double) * n;
-        off = o;    o += sizeof(double) * n;
-        term = o;   o += sizeof(double) * n;
-        e = o;      o += sizeof(double) * n;
-        eta = o;    o += sizeof(double) * n;
-        sorted = o; o += sizeof(double) * n;
-        cfg = o;    o += sizeof(uint32_t) * (size_t)cap * W;
-        newc = o;   o += sizeof(uint32_t) * ((W + 1) & ~1);
-        total = (o + 15) & ~(size_t)15;
-    }
+    static constexpr int LDR = round8(LD);      // rows of A (padded so 8-row batches stay inside)
+    static constexpr int NA = round8(LD) + 8;   // per-active-entry vectors
+    static constexpr int NV = NK * 64;          // per-variable vectors
+    static constexpr int CAPR = round8(LD - 1) + 8;  // stored configurations (rows of cfg)
+    static constexpr size_t A = 0;
+    static constexpr size_t z = A + sizeof(double) * (size_t)LDR * LD;
+    static constexpr size_t dist = z + sizeof(double) * NA;
+    static constexpr size_t bsc = dist + sizeof(double) * NA;
+    static constexpr size_t d = bsc + sizeof(double) * NA;
+    static constexpr size_t r = d + sizeof(double) * NA;
+    static constexpr size_t t1 = r + sizeof(double) * NA;
+    static constexpr size_t prod = t1 + sizeof(double) * NA;
+    static constexpr size_t c0 = prod + sizeof(double) * NA;
+    static constexpr size_t c1 = c0 + sizeof(double) * NV;
+    static constexpr size_t c2 = c1 + sizeof(double) * NV;
+    static constexpr size_t e = c2 + sizeof(double) * NV;
+    static constexpr size_t cfg = e + sizeof(double) * NV;
+    static constexpr size_t newc = cfg + sizeof(uint32_t) * (size_t)CAPR * WT;
+    static constexpr size_t total = (newc + sizeof(uint32_t) * 4 + 15) & ~(size_t)15;
 };
 
 __device__ __forceinline__ void wsync() { __syncthreads(); }  // single-wave workgroup
@@ -75,163 +87,299 @@ __device__ __forceinline__ double bcast_f64(double v, int lane)
     return __builtin_bit_cast(double, b);
 }
 
-// serial left-to-right sum of an LDS array, same bits in every lane
-__device__ __forceinline__ double serial_sum(const double* a, int len)
+// 8 consecutive doubles from a 16-byte aligned LDS address (4 x ds_read_b128)
+__device__ __forceinline__ void ld8(const double* p, double (&v)[8])
 {
-    double v = 0.0;
-#pragma unroll 16
-    for (int k = 0; k < len; ++k) v += a[k];
-    return v;
+    const dbl2* q = reinterpret_cast<const dbl2*>(p);
+    const dbl2 t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
+    v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
+    v[4] = t2.x; v[5] = t2.y; v[6] = t3.x; v[7] = t3.y;
 }
 
-// Linear oracle on potentials on[]/off[] (LDS) -> newc[] (LDS bit words), returns the value.
-// budget <= 0: lvmhelpers/bernoulli.h:14-35; budget > 0: lvmhelpers/budget.h:24-85.
-__device__ double maximize(const SmLayout& L, char* sm, int budget, int lane)
+// Serial left-to-right sums of NC zero-padded LDS arrays (len8 a multiple of 8, >= 8), all chains
+// advancing together; every lane gets the same bits.
+template <int NC>
+__device__ __forceinline__ void serial_sums(const double* const (&arr)[NC], int len8, double (&acc)[NC])
 {
-    const double* on = (const double*)(sm + L.on);
-    const double* off = (const double*)(sm + L.off);
-    double* term = (double*)(sm + L.term);
-    double* e = (double*)(sm + L.e);
-    double* sorted = (double*)(sm + L.sorted);
-    uint32_t* newc = (uint32_t*)(sm + L.newc);
-    const int n = L.n;
-    double value;
-    if (budget <= 0) {
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            bool bit = false;
-            if (k < n) {
-                const double a = on[k], b = off[k];
-                bit = a > b;
-                term[k] = bit ? a : b;
-            }
-            const unsigned long long m = __ballot(bit);
-            if (lane == 0) {
-                newc[(k0 >> 5)] = (uint32_t)m;
-                if ((k0 >> 5) + 1 < L.W) newc[(k0 >> 5) + 1] = (uint32_t)(m >> 32);
-            }
-        }
-        wsync();
-        value = serial_sum(term, n);
-        wsync();
-        return value;
+    double a[NC][8], b[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { acc[c] = 0.0; ld8(arr[c], a[c]); }
+    int k0 = 0;
+    for (;;) {
+        int kn = k0 + 8 < len8 ? k0 + 8 : len8 - 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ld8(arr[c] + kn, b[c]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += a[c][u];
+        k0 += 8;
+        if (k0 >= len8) break;
+        kn = k0 + 8 < len8 ? k0 + 8 : len8 - 8;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ld8(arr[c] + kn, a[c]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += b[c][u];
+        k0 += 8;
+        if (k0 >= len8) break;
     }
-    // budget factor
-    int num_active = 0;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-        const int k = k0 + lane;
-        bool pos = false;
-        if (k < n) {
-            const double ev = on[k] - off[k];
-            e[k] = ev;
-            pos = ev > 0;
-            term[k] = pos ? ev : 0.0;
-        }
-        const unsigned long long m = __ballot(pos);
-        num_active += __popcll(m);
+}
+
+// sum_{j < cnt8} col[j*LD] * b[j], serial in j (product rounded, then added); b zero-padded.
+template <int LD>
+__device__ __forceinline__ double matvec_col(const double* col, const double* b, int cnt8)
+{
+    double acc = 0.0;
+    double a0[8], b0[8], a1[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a0[u] = col[u * LD];
+    ld8(b, b0);
+    int j0 = 0;
+    for (;;) {
+        int jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a1[u] = col[(jn + u) * LD];
+        ld8(b + jn, b1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double t = a0[u] * b0[u]; acc += t; }
+        j0 += 8;
+        if (j0 >= cnt8) break;
+        jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[u] = col[(jn + u) * LD];
+        ld8(b + jn, b0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const double t = a1[u] * b1[u]; acc += t; }
+        j0 += 8;
+        if (j0 >= cnt8) break;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ double f64_from_hi(int hi)
+{
+    return __builtin_bit_cast(double, (unsigned long long)(unsigned)hi << 32);
+}
+
+// mon[q] = sum_i [bit k of cfg_i] z_i, moff[q] = sum_i [bit k off] z_i for k = lane + 64 q, serial
+// in i as UpdateMarginalsFromConfiguration is called (bernoulli.h:58-73); z zero-padded to m8.
+template <int WT, int NK>
+__device__ __forceinline__ void marginals(const uint32_t* cfg, const double* z, int m8, int lane,
+                                          double (&mon)[NK], double (&moff)[NK])
+{
+    int wi[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+        int w = 2 * q + (lane >> 5);
+        wi[q] = w < WT ? w : WT - 1;
+        mon[q] = 0.0;
+        moff[q] = 0.0;
+    }
+    const int sh = lane & 31;
+    for (int i0 = 0; i0 < m8; i0 += 8) {
+        double zz[8];
+        uint32_t w[NK][8];
+        ld8(z + i0, zz);
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[q][u] = cfg[(i0 + u) * WT + wi[q]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int msk = __builtin_amdgcn_sbfe(w[q][u], sh, 1);       // 0 or -1
+                const int fh = msk & 0x3ff00000;                              // 1.0 or 0.0 (high word)
+                const double f_on = f64_from_hi(fh), f_off = f64_from_hi(fh ^ 0x3ff00000);
+                mon[q] = __builtin_fma(zz[u], f_on, mon[q]);                   // == mon + z or mon + 0
+                moff[q] = __builtin_fma(zz[u], f_off, moff[q]);
+            }
+    }
+}
+
+template <int LD, int WT, int NK>
+struct Sm {
+    using L = SmLayout<LD, WT, NK>;
+    char* sm;
+    int n, n8, W, lane;
+    __device__ __forceinline__ double* A() const { return (double*)(sm + L::A); }
+    __device__ __forceinline__ double* z() const { return (double*)(sm + L::z); }
+    __device__ __forceinline__ double* dist() const { return (double*)(sm + L::dist); }
+    __device__ __forceinline__ double* bsc() const { return (double*)(sm + L::bsc); }
+    __device__ __forceinline__ double* d() const { return (double*)(sm + L::d); }
+    __device__ __forceinline__ double* r() const { return (double*)(sm + L::r); }
+    __device__ __forceinline__ double* t1() const { return (double*)(sm + L::t1); }
+    __device__ __forceinline__ double* prod() const { return (double*)(sm + L::prod); }
+    __device__ __forceinline__ double* c0() const { return (double*)(sm + L::c0); }
+    __device__ __forceinline__ double* c1() const { return (double*)(sm + L::c1); }
+    __device__ __forceinline__ double* c2() const { return (double*)(sm + L::c2); }
+    __device__ __forceinline__ double* e() const { return (double*)(sm + L::e); }
+    __device__ __forceinline__ uint32_t* cfg() const { return (uint32_t*)(sm + L::cfg); }
+    __device__ __forceinline__ uint32_t* newc() const { return (uint32_t*)(sm + L::newc); }
+
+    __device__ __forceinline__ void put_bits(int q, unsigned long long mask) const
+    {
         if (lane == 0) {
-            newc[(k0 >> 5)] = (uint32_t)m;
-            if ((k0 >> 5) + 1 < L.W) newc[(k0 >> 5) + 1] = (uint32_t)(m >> 32);
+            uint32_t* nc = newc();
+            if (2 * q < WT) nc[2 * q] = (uint32_t)mask;
+            if (2 * q + 1 < WT) nc[2 * q + 1] = (uint32_t)(mask >> 32);
         }
     }
-    wsync();
-    value = 0.0;
-    double sum = 0.0;  // adding 0.0 for the inactive ones changes nothing
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) {  // two independent serial chains, interleaved
-        value += off[k];
-        sum += term[k];
-    }
-    if (num_active > budget) {
-        // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
-        int cnt_sel = 0;
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            bool sel = false;
-            if (k < n) {
-                const double ek = e[k];
-                int rank = 0;
-#pragma unroll 8
-                for (int j = 0; j < n; ++j) {
-                    const double ej = e[j];
-                    rank += ((-ej < -ek) || (!(-ek < -ej) && j < k)) ? 1 : 0;
+
+    // Linear oracle on the per-lane potentials on[]/off[] (variable k = lane + 64 q) -> newc[]
+    // (LDS bit words).  Returns the oracle's value and Evaluate(newc) under eta = [x; 0]
+    // (bernoulli.h:38-54: sum of eta over the on-bits in index order).
+    // budget <= 0: lvmhelpers/bernoulli.h:14-35; budget > 0: lvmhelpers/budget.h:24-85.
+    __device__ __forceinline__ void maximize(const double (&on)[NK], const double (&off)[NK],
+                                             const double (&eta)[NK], int budget, double& value,
+                                             double& evalsum) const
+    {
+        double* a0 = c0();
+        double* a1 = c1();
+        double* a2 = c2();
+        if (budget <= 0) {
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int k = lane + 64 * q;
+                const bool valid = k < n;
+                const bool bit = valid && (on[q] > off[q]);
+                a0[k] = valid ? (bit ? on[q] : off[q]) : 0.0;
+                a1[k] = bit ? eta[q] : 0.0;
+                put_bits(q, __ballot(bit));
+            }
+            wsync();
+            const double* const arr[2] = {a0, a1};
+            double acc[2];
+            serial_sums<2>(arr, n8, acc);
+            value = acc[0];
+            evalsum = acc[1];
+            wsync();
+            return;
+        }
+        // budget factor
+        double ev[NK];
+        bool sel[NK];
+        int num_active = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = lane + 64 * q;
+            const bool valid = k < n;
+            ev[q] = on[q] - off[q];
+            sel[q] = valid && (ev[q] > 0);
+            a0[k] = valid ? off[q] : 0.0;
+            a1[k] = sel[q] ? ev[q] : 0.0;  // adding 0.0 for the inactive ones changes nothing
+            e()[k] = valid ? ev[q] : -INFINITY;  // padding never outranks anything
+            num_active += __popcll(__ballot(sel[q]));
+        }
+        if (num_active > budget) {
+            wsync();
+            // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
+            const double* ee = e();
+            int rank[NK];
+#pragma unroll
+            for (int q = 0; q < NK; ++q) rank[q] = 0;
+            for (int j0 = 0; j0 < n8; j0 += 8) {
+                double ej[8];
+                ld8(ee + j0, ej);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = j0 + u;
+#pragma unroll
+                    for (int q = 0; q < NK; ++q) {
+                        const int k = lane + 64 * q;
+                        rank[q] += ((ej[u] > ev[q]) || (ej[u] == ev[q] && j < k)) ? 1 : 0;
+                    }
                 }
-                sorted[rank] = ek;
-                sel = (rank < budget) && !(ek < 0);
             }
-            const unsigned long long m = __ballot(sel);
-            cnt_sel += __popcll(m);
-            if (lane == 0) {
-                newc[(k0 >> 5)] = (uint32_t)m;
-                if ((k0 >> 5) + 1 < L.W) newc[(k0 >> 5) + 1] = (uint32_t)(m >> 32);
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int k = lane + 64 * q;
+                const bool valid = k < n;
+                sel[q] = valid && (rank[q] < budget) && !(ev[q] < 0);
+                if (valid) a1[rank[q]] = sel[q] ? ev[q] : 0.0;  // sorted, zero beyond the selection
             }
+        }
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = lane + 64 * q;
+            a2[k] = sel[q] ? eta[q] : 0.0;
+            put_bits(q, __ballot(sel[q]));
         }
         wsync();
-        sum = serial_sum(sorted, cnt_sel);
+        const double* const arr[3] = {a0, a1, a2};
+        double acc[3];
+        serial_sums<3>(arr, n8, acc);
+        value = acc[0] + acc[1];
+        evalsum = acc[2];
+        wsync();
     }
-    wsync();
-    return value + sum;
-}
+};
 
-// Evaluate (bernoulli.h:38-54) under eta = [x; 0]: sum over the on-bits in index order.
-__device__ __forceinline__ double evaluate(const SmLayout& L, char* sm, const uint32_t* c)
-{
-    const double* eta = (const double*)(sm + L.eta);
-    double v = 0.0;
-    for (int w = 0; w < L.W; ++w) {
-        const uint32_t bits = c[w];
-        const int k0 = w * 32, kn = (L.n - k0 < 32) ? (L.n - k0) : 32;
-#pragma unroll 8
-        for (int b = 0; b < kn; ++b) v += ((bits >> b) & 1u) ? eta[k0 + b] : 0.0;
-    }
-    return v;
-}
-
+template <int LD, int WT, int NK>
 __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     const float* __restrict__ scores, const double* __restrict__ init_scores, int budget,
     int max_iter, int64_t B, int n, uint32_t* __restrict__ aset_bits, float* __restrict__ p_out,
     int32_t* __restrict__ alen, double* __restrict__ inv_a, int32_t* __restrict__ iters,
     int32_t* __restrict__ status)
 {
-    extern __shared__ __align__(16) char sm[];
-    const SmLayout L(n);
+    using L = SmLayout<LD, WT, NK>;
+    extern __shared__ __align__(16) char smem[];
+    Sm<LD, WT, NK> S;
+    S.sm = smem;
+    S.n = n;
+    S.n8 = round8(n);
+    S.W = (n + 31) / 32;
+    S.lane = threadIdx.x;
     const int lane = threadIdx.x;
     const int64_t s = blockIdx.x;
-    const int cap = L.cap, ld = L.ld, W = L.W;
-    double* A = (double*)(sm + L.A);
-    double* z = (double*)(sm + L.z);
-    double* dist = (double*)(sm + L.dist);
-    double* bsc = (double*)(sm + L.bsc);
-    double* d = (double*)(sm + L.d);
-    double* r = (double*)(sm + L.r);
-    double* on = (double*)(sm + L.on);
-    double* off = (double*)(sm + L.off);
-    double* eta = (double*)(sm + L.eta);
-    uint32_t* cfg = (uint32_t*)(sm + L.cfg);
-    uint32_t* newc = (uint32_t*)(sm + L.newc);
+    const int cap = n + 1, W = S.W;
+    double* A = S.A();
+    double* z = S.z();
+    double* dist = S.dist();
+    double* bsc = S.bsc();
+    double* d = S.d();
+    double* r = S.r();
+    double* t1 = S.t1();
+    double* prod = S.prod();
+    uint32_t* cfg = S.cfg();
+    uint32_t* newc = S.newc();
 
-    for (int k = lane; k < n; k += 64) {
-        const double x = (double)scores[s * n + k];
-        eta[k] = x;
-        if (init_scores) {  // InitActiveSetFromScores: Maximize(init)
-            on[k] = init_scores[s * 2 * n + k];
-            off[k] = init_scores[s * 2 * n + n + k];
-        } else {            // SolveQP on an empty active set: Maximize(eta)
-            on[k] = x;
-            off[k] = 0.0;
+    // zero everything: padded steps of the serial loops rely on zeros / finite values
+    {
+        dbl2* all = reinterpret_cast<dbl2*>(smem);
+        const dbl2 zero2 = {0.0, 0.0};
+        for (int i = lane; i < (int)(L::total / 16); i += 64) all[i] = zero2;
+    }
+    double eta[NK], on[NK], off[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+        const int k = lane + 64 * q;
+        eta[q] = 0.0; on[q] = 0.0; off[q] = 0.0;
+        if (k < n) {
+            const double x = (double)scores[s * n + k];
+            eta[q] = x;
+            if (init_scores) {  // InitActiveSetFromScores: Maximize(init)
+                on[q] = init_scores[s * 2 * n + k];
+                off[q] = init_scores[s * 2 * n + n + k];
+            } else {            // SolveQP on an empty active set: Maximize(eta)
+                on[q] = x;
+                off[q] = 0.0;
+            }
         }
     }
     wsync();
-    (void)maximize(L, sm, budget, lane);
-    for (int w = lane; w < W; w += 64) cfg[w] = newc[w];
-    if (lane == 0) {
-        dist[0] = 1.0;
-        A[0 * ld + 0] = -(double)n; A[0 * ld + 1] = 1.0; A[1 * ld + 0] = 1.0; A[1 * ld + 1] = 0.0;
-    }
-    wsync();
     {
-        const double v = evaluate(L, sm, cfg);
-        if (lane == 0) { bsc[0] = 1.0; bsc[1] = v; }
+        double value, evalsum;
+        S.maximize(on, off, eta, budget, value, evalsum);
+        if (lane < WT) cfg[lane] = newc[lane];
+        if (lane == 0) {
+            dist[0] = 1.0;
+            A[0 * LD + 0] = -(double)n; A[0 * LD + 1] = 1.0; A[1 * LD + 0] = 1.0; A[1 * LD + 1] = 0.0;
+            bsc[0] = 1.0;
+            bsc[1] = evalsum;
+        }
     }
     int m = 1;
     wsync();
@@ -244,12 +392,17 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         bool same = true;
         if (changed) {
             // [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)]
+            const int cnt8 = round8(m + 1);
             double t0 = 0.0;
-            for (int c = lane; c <= m; c += 64) {
-                double acc = 0.0;
-#pragma unroll 8
-                for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bsc[j];
-                if (c == 0) t0 = acc; else z[c - 1] = acc;
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int c = lane + 64 * q;
+                if (q * 64 <= cnt8) {   // uniform: chunks that hold an output or padding to clear
+                    const int cc = c < LD ? c : LD - 1;
+                    const double acc = matvec_col<LD>(A + cc, bsc, cnt8);
+                    if (c == 0) t0 = acc;
+                    else if (c - 1 < L::NA) z[c - 1] = (c <= m) ? acc : 0.0;
+                }
             }
             tau = bcast_f64(t0, 0);
             same = false;
@@ -257,31 +410,35 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             SM_T(0);
         }
         if (same) {
-            for (int k = lane; k < n; k += 64) {
-                double mon = 0.0, moff = 0.0;
-                const uint32_t* cw = cfg + (k >> 5);
-                const int sh = k & 31;
-#pragma unroll 8
-                for (int i = 0; i < m; ++i) {
-                    const double zi = z[i];
-                    const bool bit = (cw[i * W] >> sh) & 1u;
-                    // x + 0.0 == x bit for bit (the sums never hold -0.0): add to both chains
-                    mon += bit ? zi : 0.0;
-                    moff += bit ? 0.0 : zi;
-                }
-                on[k] = eta[k] - mon;
-                off[k] = 0.0 - moff;
+            double mon[NK], moff[NK];
+            marginals<WT, NK>(cfg, z, round8(m), lane, mon, moff);
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                on[q] = eta[q] - mon[q];
+                off[q] = 0.0 - moff[q];
             }
-            wsync();
             SM_T(1);
-            const double value = maximize(L, sm, budget, lane);
+            double value, evalsum;
+            S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
             if (value <= tau + 1e-9) { st = SM_CONVERGED; break; }
+            // SameConfiguration against every active entry + r = [1; CountCommonValues(cfg_i, new)]
             bool dup = false;
-            for (int i = lane; i < m; i += 64) {
-                bool eq = true;
-                for (int w = 0; w < W; ++w) eq = eq && (cfg[i * W + w] == newc[w]);
-                dup = dup || eq;
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int i = lane + 64 * q;   // KKT index: 0 -> 1.0, i >= 1 -> configuration i-1
+                if (i < L::NA) {
+                    double ri = 0.0;
+                    if (i == 0) ri = 1.0;
+                    else if (i <= m) {
+                        int diff = 0;
+#pragma unroll
+                        for (int w = 0; w < WT; ++w) diff += __popc(cfg[(i - 1) * WT + w] ^ newc[w]);
+                        dup = dup || (diff == 0);
+                        ri = (double)(n - diff);
+                    }
+                    r[i] = ri;
+                }
             }
             if (__any(dup)) { st = SM_DUPLICATE; break; }
             if (m >= cap) { st = SM_SINGULAR; break; }
@@ -291,60 +448,90 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 if (i == m) z[i] = 0.0;
                 dist[i] = zi;
             }
-            // InvertAfterInsertion
-            for (int i = lane; i <= m; i += 64) {
-                double ri = 1.0;
-                if (i > 0) {
-                    int diff = 0;
-                    for (int w = 0; w < W; ++w) diff += __popc(cfg[(i - 1) * W + w] ^ newc[w]);
-                    ri = (double)(n - diff);
-                }
-                r[i] = ri;
-            }
             wsync();
             SM_T(3);
-            for (int j = lane; j <= m; j += 64) {
-                double acc = 0.0;
-#pragma unroll 8
-                for (int i = 0; i <= m; ++i) {
-                    const double ri = r[i];
-                    const double t = acc + A[i * ld + j] * ri;
-                    acc = (ri == 0.0) ? acc : t;  // terms with r_i == 0 are skipped (oracle C4)
+            // InvertAfterInsertion: d = invA r
+            const int cnt8 = round8(m + 1);
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int j = lane + 64 * q;
+                if (q * 64 <= cnt8 && j < L::NA) {
+                    const int jj = j < LD ? j : LD - 1;
+                    const double acc = matvec_col<LD>(A + jj, r, cnt8);
+                    const double dj = (j <= m) ? acc : 0.0;
+                    d[j] = dj;
+                    prod[j] = r[j] * dj;   // r is 0 beyond m
                 }
-                d[j] = acc;
             }
             wsync();
             SM_T(4);
-            double sden = (double)n;
-#pragma unroll 8
-            for (int j = 0; j <= m; ++j) sden -= r[j] * d[j];
+            double sden;
+            {
+                // s = n - sum_j r_j d_j, serial
+                double acc = (double)n;
+                double a[8], b[8];
+                ld8(prod, a);
+                int k0 = 0;
+                for (;;) {
+                    int kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
+                    ld8(prod + kn, b);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc -= a[u];
+                    k0 += 8;
+                    if (k0 >= cnt8) break;
+                    kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
+                    ld8(prod + kn, a);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc -= b[u];
+                    k0 += 8;
+                    if (k0 >= cnt8) break;
+                }
+                sden = acc;
+            }
             if (sden <= 1e-9 && sden >= -1e-9) { st = SM_SINGULAR; break; }
             const double invs = 1.0 / sden;
-            SM_T(5);
-            for (int j = lane; j <= m; j += 64) {  // lane owns column j; d[] is read-only here
-                const double dj = d[j];
-                double* __restrict__ col = A + j;          // A and d never overlap
-                const double* __restrict__ dd = d;
-#pragma unroll 8
-                for (int i = 0; i <= m; ++i) col[i * ld] = col[i * ld] + invs * dd[i] * dj;
+            // t1 = invs * d (zero beyond m)
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int i = lane + 64 * q;
+                if (i < L::NA) t1[i] = (i <= m) ? invs * d[i] : 0.0;
             }
+            wsync();
+            SM_T(5);
+            // A[i][j] += (invs d_i) d_j : lane owns column j
+#pragma unroll
+            for (int q = 0; q * 64 < LD; ++q) {
+                const int j = lane + 64 * q;
+                if (j <= m) {
+                    const double dj = d[j];
+                    double* col = A + j;
+                    for (int i0 = 0; i0 < cnt8; i0 += 8) {
+                        double a[8], t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) a[u] = col[(i0 + u) * LD];
+                        ld8(t1 + i0, t);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { const double pr = t[u] * dj; a[u] = a[u] + pr; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) col[(i0 + u) * LD] = a[u];
+                    }
+                }
+            }
+            wsync();
             for (int i = lane; i <= m; i += 64) {
                 const double v = -invs * d[i];
-                A[i * ld + (m + 1)] = v;
-                A[(m + 1) * ld + i] = v;
+                A[i * LD + (m + 1)] = v;
+                A[(m + 1) * LD + i] = v;
             }
-            if (lane == 0) A[(m + 1) * ld + (m + 1)] = invs;
-            for (int w = lane; w < W; w += 64) cfg[m * W + w] = newc[w];
-            wsync();
-            SM_T(6);
-            {
-                const double v = evaluate(L, sm, cfg + m * W);
-                if (lane == 0) bsc[m + 1] = v;
+            if (lane == 0) {
+                A[(m + 1) * LD + (m + 1)] = invs;
+                bsc[m + 1] = evalsum;
             }
+            if (lane < WT) cfg[m * WT + lane] = newc[lane];
             ++m;
             changed = true;
             wsync();
-            SM_T(7);
+            SM_T(6);
         } else {
             // blocking constraints: argmin of dist/(dist - z) over {z < dist}, first index on ties
             double best = INFINITY;
@@ -386,45 +573,59 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 // InvertAfterRemoval
                 const int ri = blocking + 1;
                 wsync();
-                const double invs = A[ri * ld + ri];
+                const double invs = A[ri * LD + ri];
                 const double sdiv = 1.0 / invs;
                 for (int i = lane; i <= m; i += 64)
-                    if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * ld + i];
+                    if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * LD + i];
                 wsync();
-                // in place with compaction: targets never pass the sources in row-major order
-                for (int i = 0; i <= m; ++i) {
-                    if (i == ri) continue;
-                    const int kk = i - (i > ri ? 1 : 0);
-                    const double dk = d[kk];
-                    for (int j0 = 0; j0 <= m; j0 += 64) {
-                        const int j = j0 + lane;
-                        double v = 0.0;
-                        const bool ok = (j <= m) && (j != ri);
-                        // one wave: LDS executes its instructions in order, so every lane's read of
-                        // this chunk precedes every lane's write below
-                        if (ok) v = A[i * ld + j];
-                        if (ok) {
-                            const int l = j - (j > ri ? 1 : 0);
-                            A[kk * ld + l] = v - invs * dk * d[l];
+                // in place with compaction: targets never pass the sources in row-major order.
+                // Rows go in batches of 4: all reads of a batch are issued before its writes (one
+                // wave: LDS executes in order), and a batch only writes rows it has already read.
+                for (int i0 = 0; i0 <= m; i0 += 4) {
+#pragma unroll
+                    for (int q = 0; q * 64 < LD; ++q) {
+                        const int j = lane + 64 * q;
+                        const bool okj = (j <= m) && (j != ri);
+                        const int l = j - (j > ri ? 1 : 0);
+                        double v[4], dk[4];
+                        const double dl = okj ? d[l] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u;
+                            const int ic = i <= m ? i : m;
+                            const int kk = ic - (ic > ri ? 1 : 0);
+                            v[u] = okj ? A[ic * LD + j] : 0.0;
+                            dk[u] = d[kk];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u;
+                            if (okj && i <= m && i != ri) {
+                                const int kk = i - (i > ri ? 1 : 0);
+                                A[kk * LD + l] = v[u] - invs * dk[u] * dl;
+                            }
                         }
                     }
                 }
                 // erase entry `blocking` from cfg / z / dist / bsc (chunks ascending: read, then write)
-                for (int i0 = blocking; i0 < m - 1; i0 += 64) {
+                for (int i0 = blocking; i0 < m; i0 += 64) {
                     const int i = i0 + lane;
                     const bool ok = i < m - 1;
+                    const bool last = i == m - 1;   // vacated slot: back to zero (padding invariant)
                     double zv = 0.0, dv = 0.0, bv = 0.0;
-                    uint32_t cw[4] = {0u, 0u, 0u, 0u};
+                    uint32_t cw[WT];
+#pragma unroll
+                    for (int w = 0; w < WT; ++w) cw[w] = 0u;
                     if (ok) {
                         zv = z[i + 1]; dv = dist[i + 1]; bv = bsc[i + 2];
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) if (w < W) cw[w] = cfg[(i + 1) * W + w];
+                        for (int w = 0; w < WT; ++w) cw[w] = cfg[(i + 1) * WT + w];
                     }
                     wsync();
-                    if (ok) {
+                    if (ok || last) {
                         z[i] = zv; dist[i] = dv; bsc[i + 1] = bv;
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) if (w < W) cfg[i * W + w] = cw[w];
+                        for (int w = 0; w < WT; ++w) cfg[i * WT + w] = cw[w];
                     }
                     wsync();
                 }
@@ -438,13 +639,16 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     wsync();
 
     // outputs
-    for (int i = lane; i < cap * W; i += 64)
-        aset_bits[s * cap * W + i] = (i < m * W) ? cfg[i] : 0u;
+    for (int i = lane; i < cap * W; i += 64) {
+        const int row = i / W, w = i - row * W;
+        aset_bits[s * cap * W + i] = (row < m) ? cfg[row * WT + w] : 0u;
+    }
     for (int i = lane; i < cap; i += 64) p_out[s * cap + i] = (i < m) ? (float)dist[i] : 0.0f;
     if (inv_a) {
-        double* o = inv_a + s * (int64_t)ld * ld;
+        const int ldo = n + 2;
+        double* o = inv_a + s * (int64_t)ldo * ldo;
         for (int i = 0; i <= m; ++i)
-            for (int j = lane; j <= m; j += 64) o[i * ld + j] = A[i * ld + j];
+            for (int j = lane; j <= m; j += 64) o[i * ldo + j] = A[i * LD + j];
     }
     if (lane == 0) {
         alen[s] = m;
@@ -490,6 +694,29 @@ __global__ __launch_bounds__(64) void sparsemap_bwd_kernel(
 
 using namespace smlvm;
 
+template <int LD, int WT, int NK>
+static int launch_sm_fwd(const float* scores, const double* init_scores, int32_t budget,
+                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                         int32_t* alen, double* inv_a, int32_t* iters, int32_t* status,
+                         hipStream_t stream)
+{
+    using L = SmLayout<LD, WT, NK>;
+    static thread_local bool configured = false;
+    if (L::total > 48 * 1024 && !configured) {
+        if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel<LD, WT, NK>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)L::total) != hipSuccess) {
+            g_last_hip_error = (int)hipGetLastError();
+            return SMLVM_ERR_HIP;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK>), dim3((unsigned)B), dim3(64), L::total,
+                       stream, scores, init_scores, budget, max_iter, B, n, aset_bits, p, alen,
+                       inv_a, iters, status);
+    return check_launch();
+}
+
 extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
                                    int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits,
                                    float* p, int32_t* alen, double* inv_a, int32_t* iters,
@@ -499,21 +726,15 @@ extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_score
     if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
     if (B == 0) return SMLVM_OK;
     if (!scores || !aset_bits || !p || !alen) return SMLVM_ERR_INVALID;
-    const SmLayout L(n);
-    static thread_local size_t configured = 0;
-    if (L.total > 48 * 1024 && L.total > configured) {
-        if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)L.total) != hipSuccess) {
-            g_last_hip_error = (int)hipGetLastError();
-            return SMLVM_ERR_HIP;
-        }
-        configured = L.total;
-    }
-    hipLaunchKernelGGL(sparsemap_fwd_kernel, dim3((unsigned)B), dim3(64), L.total,
-                       (hipStream_t)stream, scores, init_scores, budget, max_iter, B, n, aset_bits, p,
-                       alen, inv_a, iters, status);
-    return check_launch();
+#define SM_GO(LD, WT, NK)                                                                         \
+    return launch_sm_fwd<LD, WT, NK>(scores, init_scores, budget, max_iter, B, n, aset_bits, p,    \
+                                     alen, inv_a, iters, status, (hipStream_t)stream)
+    if (n <= 8) SM_GO(10, 1, 1);
+    if (n <= 16) SM_GO(18, 1, 1);
+    if (n <= 32) SM_GO(34, 1, 1);
+    if (n <= 64) SM_GO(66, 2, 1);
+    SM_GO(130, 4, 2);
+#undef SM_GO
 }
 
 extern "C" int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,

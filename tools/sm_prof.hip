@@ -1,5 +1,6 @@
 // Diagnostic: cycles per phase of the SparseMAP solver (never shipped; build:
-// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSMLVM_SM_PROF tools/sm_prof.hip -o tools/sm_prof)
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSMLVM_SM_PROF tools/sm_prof.hip -o tools/sm_prof;
+// without -DSMLVM_SM_PROF (-o tools/sm_time) it only times the launch, for rocprofv3 --pmc runs)
 #include "../sparse-marginalization-lvm_amd/csrc/sparsemap.hip"
 #include <cstdio>
 #include <vector>
@@ -24,19 +25,26 @@ int main(int argc, char** argv)
     hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dinit, init.data(), init.size() * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
+#ifdef SMLVM_SM_PROF
         unsigned long long zero[16] = {0};
         hipMemcpyToSymbol(HIP_SYMBOL(smlvm::g_prof), zero, sizeof zero);
+#endif
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         int rc = smlvm_sparsemap_fwd(dx, dinit, budget, 300, B, n, dbits, dp, dalen, dinv, dit, dst, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long prof[16];
+        unsigned long long prof[16] = {0};
+#ifdef SMLVM_SM_PROF
         hipMemcpyFromSymbol(prof, HIP_SYMBOL(smlvm::g_prof), sizeof prof);
+#endif
         std::vector<int> it(B); hipMemcpy(it.data(), dit, B * 4, hipMemcpyDeviceToHost);
         long long tot = 0; for (int v : it) tot += v;
         printf("rc=%d  %.3f ms  total iters %lld\n", rc, ms, tot);
-        const char* names[] = {"solve z", "marginals", "maximize", "dup+r", "d=invA r", "sden", "A update", "evaluate", "blocking(no)", "blocking+removal"};
+#ifndef SMLVM_SM_PROF
+        continue;
+#endif
+        const char* names[] = {"solve z", "marginals", "maximize+eval", "dup+r+push", "d=invA r", "sden+t1", "A update+append", "-", "blocking(no)", "blocking+removal"};
         unsigned long long sum = 0; for (int k = 0; k < 10; ++k) sum += prof[k];
         for (int k = 0; k < 10; ++k) printf("  %-18s %12llu ticks  %5.1f%%\n", names[k], prof[k], 100.0 * prof[k] / sum);
         printf("  ticks per iter: %.0f (clock64 = 100 MHz wall clock on gfx9?)\n", (double)sum / tot);
