@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SMLVM_ABI_VERSION 1
+#define SMLVM_ABI_VERSION 2
 
 #define SMLVM_OK 0
 #define SMLVM_ERR_INVALID (-1)     /* null pointer, negative size, bad combination of arguments */
@@ -116,12 +116,17 @@ int smlvm_binary_topk_batched(const float* scores, float* configs, float* topsco
  *   inv_a     [B, ld, ld] fp64     cached inverse KKT matrix (rows/cols 0..alen[b] written); the
  *                                  state the reference keeps on ctx.f between forward and backward
  *   iters     [B] int32, status [B] int32 (0 converged, 1 max_iter, 2 singular, 3 duplicate); nullable
+ *   workspace : smlvm_sparsemap_fwd_workspace_bytes(B, n, inv_a != NULL) bytes, 8-byte aligned
+ *               (0 for n <= 64: may be NULL).  For n > 64 the batch runs in tiers of growing LDS
+ *               footprint (4, 2, 1 samples per CU); a sample whose active set outgrows a tier parks
+ *               its solver state here and the next launch resumes it -- results do not depend on it.
  * Backward: dp [B, cap] fp32 -> dscores [B, n] fp32.
  */
+size_t smlvm_sparsemap_fwd_workspace_bytes(int64_t B, int32_t n, int32_t with_inv_a);
 int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
                         int32_t* alen, double* inv_a, int32_t* iters, int32_t* status,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
                         const double* inv_a, int64_t B, int32_t n, float* dscores, void* stream);
 

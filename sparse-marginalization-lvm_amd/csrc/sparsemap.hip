@@ -41,21 +41,23 @@ constexpr int round8(int v) { return (v + 7) & ~7; }
 template <int LD, int WT, int NK>
 struct SmLayout {
     static constexpr int LDR = round8(LD);      // rows of A (padded so 8-row batches stay inside)
-    static constexpr int NA = round8(LD) + 8;   // per-active-entry vectors
+    static constexpr int NA = round8(LD);       // per-active-entry vectors
     static constexpr int NV = NK * 64;          // per-variable vectors
-    static constexpr int CAPR = round8(LD - 1) + 8;  // stored configurations (rows of cfg)
+    static constexpr int CAPR = round8(LD - 1);  // stored configurations (rows of cfg)
     static constexpr size_t A = 0;
     static constexpr size_t z = A + sizeof(double) * (size_t)LDR * LD;
     static constexpr size_t dist = z + sizeof(double) * NA;
     static constexpr size_t bsc = dist + sizeof(double) * NA;
     static constexpr size_t d = bsc + sizeof(double) * NA;
     static constexpr size_t r = d + sizeof(double) * NA;
-    static constexpr size_t t1 = r + sizeof(double) * NA;
-    static constexpr size_t prod = t1 + sizeof(double) * NA;
-    static constexpr size_t c0 = prod + sizeof(double) * NA;
-    static constexpr size_t c1 = c0 + sizeof(double) * NV;
-    static constexpr size_t c2 = c1 + sizeof(double) * NV;
+    // c0..c2, e: the linear oracle's arrays; t1 / prod (insertion only) share the first two
+    static constexpr int NC = NV > NA ? NV : NA;
+    static constexpr size_t c0 = r + sizeof(double) * NA;
+    static constexpr size_t c1 = c0 + sizeof(double) * NC;
+    static constexpr size_t c2 = c1 + sizeof(double) * NC;
     static constexpr size_t e = c2 + sizeof(double) * NV;
+    static constexpr size_t t1 = c0;
+    static constexpr size_t prod = c1;
     static constexpr size_t cfg = e + sizeof(double) * NV;
     static constexpr size_t newc = cfg + sizeof(uint32_t) * (size_t)CAPR * WT;
     static constexpr size_t total = (newc + sizeof(uint32_t) * 4 + 15) & ~(size_t)15;
@@ -77,6 +79,11 @@ __device__ unsigned long long g_prof[16];
 #define SM_T(k) do { } while (0)
 #define SM_T0() do { } while (0)
 #endif
+
+// Every lane holds the same bits; tell the compiler (scalar registers, scalar branches).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ double uni(double v) { return readlane_f64(v, 0); }
 
 __device__ __forceinline__ double bcast_f64(double v, int lane)
 {
@@ -273,7 +280,7 @@ struct Sm {
             e()[k] = valid ? ev[q] : -INFINITY;  // padding never outranks anything
             num_active += __popcll(__ballot(sel[q]));
         }
-        if (num_active > budget) {
+        if (uni(num_active > budget)) {
             wsync();
             // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
             const double* ee = e();
@@ -321,9 +328,13 @@ template <int LD, int WT, int NK>
 __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     const float* __restrict__ scores, const double* __restrict__ init_scores, int budget,
     int max_iter, int64_t B, int n, uint32_t* __restrict__ aset_bits, float* __restrict__ p_out,
-    int32_t* __restrict__ alen, double* __restrict__ inv_a, int32_t* __restrict__ iters,
-    int32_t* __restrict__ status)
+    int32_t* __restrict__ alen, double* __restrict__ a_out, int32_t* __restrict__ iters,
+    int32_t* __restrict__ status, int resume, int32_t* __restrict__ ws_state,
+    int32_t* __restrict__ ws_it, double* __restrict__ ws_tau, double* __restrict__ ws_vec)
 {
+    // Tiers (n > 64): the first launch runs every sample with a small LD (several samples per CU);
+    // a sample whose active set outgrows it parks its state (a_out, aset_bits, alen, ws_*) and a
+    // later launch with a larger LD (resume = 1) picks it up at the top of the same iteration.
     using L = SmLayout<LD, WT, NK>;
     extern __shared__ __align__(16) char smem[];
     Sm<LD, WT, NK> S;
@@ -334,7 +345,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     S.lane = threadIdx.x;
     const int lane = threadIdx.x;
     const int64_t s = blockIdx.x;
-    const int cap = n + 1, W = S.W;
+    const int cap = n + 1, W = S.W, ldo = n + 2;
+    if (resume && ws_state[s] != 1) return;   // whole wave: finished in an earlier tier
     double* A = S.A();
     double* z = S.z();
     double* dist = S.dist();
@@ -370,7 +382,10 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         }
     }
     wsync();
-    {
+    int m = 1, it = 0;
+    bool changed = true;
+    double tau = 0.0;
+    if (!resume) {
         double value, evalsum;
         S.maximize(on, off, eta, budget, value, evalsum);
         if (lane < WT) cfg[lane] = newc[lane];
@@ -380,15 +395,30 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             bsc[0] = 1.0;
             bsc[1] = evalsum;
         }
+    } else {
+        m = uni(alen[s]);
+        it = uni(ws_it[s]);
+        tau = uni(ws_tau[s]);
+        changed = false;   // parked at the top of an insertion pass
+        const double* ai = a_out + s * (int64_t)ldo * ldo;
+        for (int i = 0; i <= m; ++i)
+            for (int j = lane; j <= m; j += 64) A[i * LD + j] = ai[i * ldo + j];
+        const double* vi = ws_vec + s * (int64_t)3 * ldo;
+        for (int i = lane; i <= m; i += 64) {
+            if (i < m) { z[i] = vi[i]; dist[i] = vi[ldo + i]; }
+            bsc[i] = vi[2 * ldo + i];
+        }
+        for (int i = lane; i < m * W; i += 64) {
+            const int row = i / W, w = i - row * W;
+            cfg[row * WT + w] = aset_bits[s * cap * W + i];
+        }
     }
-    int m = 1;
     wsync();
 
     SM_T0();
-    bool changed = true;
-    int st = SM_MAXITER, it;
-    double tau = 0.0;
-    for (it = 0; it < max_iter; ++it) {
+    int st = SM_MAXITER;
+    bool overflow = false;
+    for (; it < max_iter; ++it) {
         bool same = true;
         if (changed) {
             // [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)]
@@ -404,7 +434,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                     else if (c - 1 < L::NA) z[c - 1] = (c <= m) ? acc : 0.0;
                 }
             }
-            tau = bcast_f64(t0, 0);
+            tau = uni(t0);
             same = false;
             wsync();
             SM_T(0);
@@ -421,7 +451,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             double value, evalsum;
             S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
-            if (value <= tau + 1e-9) { st = SM_CONVERGED; break; }
+            if (uni(value <= tau + 1e-9)) { st = SM_CONVERGED; break; }
             // SameConfiguration against every active entry + r = [1; CountCommonValues(cfg_i, new)]
             bool dup = false;
 #pragma unroll
@@ -442,6 +472,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             }
             if (__any(dup)) { st = SM_DUPLICATE; break; }
             if (m >= cap) { st = SM_SINGULAR; break; }
+            if (m + 2 > LD) { overflow = true; break; }   // next tier redoes this pass
             // z.push_back(0); distribution = z
             for (int i = lane; i <= m; i += 64) {
                 const double zi = (i < m) ? z[i] : 0.0;
@@ -488,8 +519,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 }
                 sden = acc;
             }
-            if (sden <= 1e-9 && sden >= -1e-9) { st = SM_SINGULAR; break; }
-            const double invs = 1.0 / sden;
+            if (uni(sden <= 1e-9 && sden >= -1e-9)) { st = SM_SINGULAR; break; }
+            const double invs = uni(1.0 / sden);
             // t1 = invs * d (zero beyond m)
 #pragma unroll
             for (int q = 0; q * 64 < L::NA; ++q) {
@@ -558,8 +589,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                     const int oi = __shfl(best_i, lane ^ o);
                     if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
                 }
-                double alpha = best;
-                const int blocking = best_i;
+                double alpha = uni(best);
+                const int blocking = uni(best_i);
                 if (alpha > 1.0) alpha = 1.0;
                 if (alpha == 1.0) {
                     for (int i = lane; i < m; i += 64) dist[i] = z[i];
@@ -573,8 +604,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 // InvertAfterRemoval
                 const int ri = blocking + 1;
                 wsync();
-                const double invs = A[ri * LD + ri];
-                const double sdiv = 1.0 / invs;
+                const double invs = uni(A[ri * LD + ri]);
+                const double sdiv = uni(1.0 / invs);
                 for (int i = lane; i <= m; i += 64)
                     if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * LD + i];
                 wsync();
@@ -644,16 +675,27 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         aset_bits[s * cap * W + i] = (row < m) ? cfg[row * WT + w] : 0u;
     }
     for (int i = lane; i < cap; i += 64) p_out[s * cap + i] = (i < m) ? (float)dist[i] : 0.0f;
-    if (inv_a) {
-        const int ldo = n + 2;
-        double* o = inv_a + s * (int64_t)ldo * ldo;
+    if (a_out) {
+        double* o = a_out + s * (int64_t)ldo * ldo;
         for (int i = 0; i <= m; ++i)
             for (int j = lane; j <= m; j += 64) o[i * ldo + j] = A[i * LD + j];
+    }
+    if (overflow) {
+        double* vo = ws_vec + s * (int64_t)3 * ldo;
+        for (int i = lane; i <= m; i += 64) {
+            if (i < m) { vo[i] = z[i]; vo[ldo + i] = dist[i]; }
+            vo[2 * ldo + i] = bsc[i];
+        }
     }
     if (lane == 0) {
         alen[s] = m;
         if (iters) iters[s] = it;
         if (status) status[s] = st;
+        if (ws_state) {
+            ws_state[s] = overflow ? 1 : 0;
+            ws_it[s] = it;
+            ws_tau[s] = tau;
+        }
     }
 }
 
@@ -694,13 +736,17 @@ __global__ __launch_bounds__(64) void sparsemap_bwd_kernel(
 
 using namespace smlvm;
 
+struct SmArgs {
+    const float* scores; const double* init_scores; int32_t budget, max_iter; int64_t B; int32_t n;
+    uint32_t* aset_bits; float* p; int32_t* alen; double* a_out; int32_t* iters; int32_t* status;
+    int32_t* ws_state; int32_t* ws_it; double* ws_tau; double* ws_vec; hipStream_t stream;
+};
+
 template <int LD, int WT, int NK>
-static int launch_sm_fwd(const float* scores, const double* init_scores, int32_t budget,
-                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
-                         int32_t* alen, double* inv_a, int32_t* iters, int32_t* status,
-                         hipStream_t stream)
+static int launch_sm_fwd(const SmArgs& a, int resume)
 {
     using L = SmLayout<LD, WT, NK>;
+    static_assert(L::total <= 160 * 1024, "LDS per CU");
     static thread_local bool configured = false;
     if (L::total > 48 * 1024 && !configured) {
         if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel<LD, WT, NK>,
@@ -711,30 +757,66 @@ static int launch_sm_fwd(const float* scores, const double* init_scores, int32_t
         }
         configured = true;
     }
-    hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK>), dim3((unsigned)B), dim3(64), L::total,
-                       stream, scores, init_scores, budget, max_iter, B, n, aset_bits, p, alen,
-                       inv_a, iters, status);
+    hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK>), dim3((unsigned)a.B), dim3(64), L::total,
+                       a.stream, a.scores, a.init_scores, a.budget, a.max_iter, a.B, a.n,
+                       a.aset_bits, a.p, a.alen, a.a_out, a.iters, a.status, resume, a.ws_state,
+                       a.ws_it, a.ws_tau, a.ws_vec);
     return check_launch();
+}
+
+// Tier sizes for 64 < n <= 128 (LDS per sample 40.5 KB -> 4 per CU, 81.7 KB -> 2 per CU, 158 KB -> 1)
+constexpr int kTier1 = 64, kTier2 = 94, kTier3 = SMLVM_SPARSEMAP_MAX_BITS + 2;
+static_assert(SmLayout<kTier1, 4, 2>::total <= 40 * 1024, "tier 1: four samples per CU");
+static_assert(SmLayout<kTier2, 4, 2>::total <= 80 * 1024, "tier 2: two samples per CU");
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t smlvm_sparsemap_fwd_workspace_bytes(int64_t B, int32_t n, int32_t with_inv_a)
+{
+    if (B <= 0 || n <= 64 || n > SMLVM_SPARSEMAP_MAX_BITS) return 0;
+    const size_t ldo = (size_t)n + 2;
+    size_t bytes = align256(sizeof(int32_t) * 2 * (size_t)B) + align256(sizeof(double) * (size_t)B) +
+                   align256(sizeof(double) * 3 * ldo * (size_t)B);
+    if (!with_inv_a) bytes += align256(sizeof(double) * ldo * ldo * (size_t)B);
+    return bytes;
 }
 
 extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
                                    int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits,
                                    float* p, int32_t* alen, double* inv_a, int32_t* iters,
-                                   int32_t* status, void* stream)
+                                   int32_t* status, void* workspace, size_t workspace_bytes,
+                                   void* stream)
 {
     if (B < 0 || n < 1 || max_iter < 0 || budget < 0) return SMLVM_ERR_INVALID;
     if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
     if (B == 0) return SMLVM_OK;
     if (!scores || !aset_bits || !p || !alen) return SMLVM_ERR_INVALID;
-#define SM_GO(LD, WT, NK)                                                                         \
-    return launch_sm_fwd<LD, WT, NK>(scores, init_scores, budget, max_iter, B, n, aset_bits, p,    \
-                                     alen, inv_a, iters, status, (hipStream_t)stream)
-    if (n <= 8) SM_GO(10, 1, 1);
-    if (n <= 16) SM_GO(18, 1, 1);
-    if (n <= 32) SM_GO(34, 1, 1);
-    if (n <= 64) SM_GO(66, 2, 1);
-    SM_GO(130, 4, 2);
-#undef SM_GO
+    SmArgs a{scores, init_scores, budget, max_iter, B, n, aset_bits, p, alen, inv_a, iters, status,
+             nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    if (n <= 8) return launch_sm_fwd<10, 1, 1>(a, 0);
+    if (n <= 16) return launch_sm_fwd<18, 1, 1>(a, 0);
+    if (n <= 32) return launch_sm_fwd<34, 1, 1>(a, 0);
+    if (n <= 64) return launch_sm_fwd<66, 2, 1>(a, 0);
+    // tiers
+    const size_t need = smlvm_sparsemap_fwd_workspace_bytes(B, n, inv_a != nullptr);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7u))
+        return SMLVM_ERR_WORKSPACE;
+    const size_t ldo = (size_t)n + 2;
+    char* w = static_cast<char*>(workspace);
+    a.ws_state = reinterpret_cast<int32_t*>(w);
+    a.ws_it = a.ws_state + B;
+    w += align256(sizeof(int32_t) * 2 * (size_t)B);
+    a.ws_tau = reinterpret_cast<double*>(w);
+    w += align256(sizeof(double) * (size_t)B);
+    a.ws_vec = reinterpret_cast<double*>(w);
+    w += align256(sizeof(double) * 3 * ldo * (size_t)B);
+    if (!inv_a) a.a_out = reinterpret_cast<double*>(w);
+    int rc = launch_sm_fwd<kTier1, 4, 2>(a, 0);
+    if (rc != SMLVM_OK) return rc;
+    if (n + 2 <= kTier2) return launch_sm_fwd<kTier2, 4, 2>(a, 1);
+    rc = launch_sm_fwd<kTier2, 4, 2>(a, 1);
+    if (rc != SMLVM_OK) return rc;
+    return launch_sm_fwd<kTier3, 4, 2>(a, 1);
 }
 
 extern "C" int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,

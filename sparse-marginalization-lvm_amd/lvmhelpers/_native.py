@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
     "smlvm_support_compact", "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
-    "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd", "smlvm_sparsemap_bwd",
+    "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
+    "smlvm_sparsemap_bwd",
     "smlvm_unpack_configs",
 ]
 
@@ -44,7 +45,9 @@ def lib():
         L.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
         L.smlvm_weighted_loss_reduce_workspace_bytes.restype = ctypes.c_size_t
         L.smlvm_weighted_loss_reduce_workspace_bytes.argtypes = [ctypes.c_int64]
-        if L.smlvm_abi_version() != 1:
+        L.smlvm_sparsemap_fwd_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_sparsemap_fwd_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        if L.smlvm_abi_version() != 2:
             raise NativeError("libsparsemarg_hip.so: ABI version mismatch")
         _lib = L
     return _lib
@@ -227,11 +230,14 @@ def sparsemap_fwd(scores, init_scores=None, budget=0, max_iter=300):
         inv_a=torch.empty((B, ld, ld), dtype=torch.float64, device=dev),
         iters=torch.empty(B, dtype=torch.int32, device=dev),
         status=torch.empty(B, dtype=torch.int32, device=dev))
+    ws_bytes = lib().smlvm_sparsemap_fwd_workspace_bytes(B, n, 1)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _check(lib().smlvm_sparsemap_fwd(
             _p(scores), _p(init_scores), _i32(int(budget)), _i32(int(max_iter)), _i64(B), _i32(n),
             _p(out["aset_bits"]), _p(out["p"]), _p(out["alen"]), _p(out["inv_a"]),
-            _p(out["iters"]), _p(out["status"]), _stream()), "smlvm_sparsemap_fwd")
+            _p(out["iters"]), _p(out["status"]), _p(ws), ctypes.c_size_t(ws_bytes), _stream()),
+            "smlvm_sparsemap_fwd")
     return out
 
 

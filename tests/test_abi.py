@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_error_strings(lib):
-    assert lib.smlvm_abi_version() == 1
+    assert lib.smlvm_abi_version() == 2
     lib.smlvm_error_string.restype = ctypes.c_char_p
     assert lib.smlvm_error_string(0) == b"ok"
     for code in (-1, -2, -3, -4):

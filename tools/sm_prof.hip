@@ -22,6 +22,7 @@ int main(int argc, char** argv)
     hipMalloc(&dx, x.size() * 4); hipMalloc(&dinit, init.size() * 8); hipMalloc(&dp, (size_t)B * cap * 4);
     hipMalloc(&dbits, (size_t)B * cap * W * 4); hipMalloc(&dalen, B * 4); hipMalloc(&dit, B * 4); hipMalloc(&dst, B * 4);
     hipMalloc(&dinv, (size_t)B * ld * ld * 8);
+    size_t wsb = smlvm_sparsemap_fwd_workspace_bytes(B, n, 1); void* dws = nullptr; hipMalloc(&dws, wsb + 8);
     hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dinit, init.data(), init.size() * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
@@ -31,7 +32,7 @@ int main(int argc, char** argv)
 #endif
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        int rc = smlvm_sparsemap_fwd(dx, dinit, budget, 300, B, n, dbits, dp, dalen, dinv, dit, dst, nullptr);
+        int rc = smlvm_sparsemap_fwd(dx, dinit, budget, 300, B, n, dbits, dp, dalen, dinv, dit, dst, dws, wsb, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         unsigned long long prof[16] = {0};
