@@ -15,7 +15,9 @@ Extra objects on that line:
                 launch stream inside the timed region) against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/, plain C, 1 thread) timed on this host on a bounded sample
   sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
-  sparsemap     batched active-set solver: samples/s and active-set iterations/s
+  sparsemap     batched active-set solver: samples/s and active-set iterations/s (N > 1: every rank
+                solves 1024 samples at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
+  sparsemap_cpu_baseline  the fp64 C oracle of the solver timed on one host core, same workload
 """
 import argparse
 import json
@@ -144,8 +146,24 @@ def cpu_baseline(K, sigma):
                       f"{t:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
-def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5):
-    g = torch.Generator(device=dev).manual_seed(77)
+def sparsemap_cpu_baseline(B, n, budget, sigma):
+    """The fp64 C oracle (1 thread) on a bounded sample of the cfg5 SparseMAP workload."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(77)
+    x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+    init = torch.rand(B, 2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(42)).numpy()
+    t0 = time.perf_counter()
+    ref = oracle.sparsemap_fwd(x, init, budget, 300)
+    t = time.perf_counter() - t0
+    return {"value": B / t, "unit": "samples/s", "cores": 1, "kind": "port",
+            "active_set_iters_per_s": float(ref["iters"].sum()) / t,
+            "sample": f"{B} samples x {n} bits, budget {budget}, N(0,{sigma}^2) scores, "
+                      f"oracle/sparsemap_oracle.c forward, {t:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
+    g = torch.Generator(device=dev).manual_seed(seed)
     x = torch.randn(B, n, device=dev, generator=g) * sigma
     init = torch.rand(B, 2 * n, dtype=torch.double,
                       generator=torch.Generator().manual_seed(42)).to(dev)
@@ -166,10 +184,15 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5):
     torch.cuda.synchronize()
     bms = e0.elapsed_time(e1) / reps
     iters = float(out["iters"].double().sum().item())
-    return {"B": B, "bits": n, "budget": budget, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
-            "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
-            "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
-            "converged_frac": float((out["status"] != 1).float().mean().item())}
+    res = {"B": B, "bits": n, "budget": budget, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
+           "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
+           "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
+           "converged_frac": float((out["status"] != 1).float().mean().item())}
+    if world > 1:  # whole-job figures: every rank solves its own B samples, slowest rank counts
+        ms_max = max_over_ranks(ms, world, dev)
+        res.update({"n_gpus": world, "B_total": B * world, "fwd_ms_max_over_ranks": ms_max,
+                    "samples_per_s": B * world / (ms_max * 1e-3)})
+    return res
 
 
 def main():
@@ -243,9 +266,15 @@ def main():
                             sparsemap_bench(native, dev, 64, 32, 16, 1.0),
                             sparsemap_bench(native, dev, 1024, 128, 0, 1.0),
                             sparsemap_bench(native, dev, 1024, 128, 64, 1.0),
-                            sparsemap_bench(native, dev, 1024, 128, 0, 3.0)]
+                            sparsemap_bench(native, dev, 1024, 128, 0, 3.0),
+                            sparsemap_bench(native, dev, 8192, 128, 0, 1.0)]
+    if world > 1 and not a.no_sweep:
+        # cfg5: batch 8192 over 8 GPUs = 1024 samples per rank at 128 bits; samples sharded, no collective
+        out["sparsemap"] = [sparsemap_bench(native, dev, 1024, 128, 0, 1.0, world=world, seed=77 + rank),
+                            sparsemap_bench(native, dev, 1024, 128, 0, 3.0, world=world, seed=77 + rank)]
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
+        out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(1024, 128, 0, 1.0)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

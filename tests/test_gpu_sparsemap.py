@@ -58,6 +58,31 @@ def test_fwd_bwd_match_oracle(dev, oracle_mod, B, n, sigma, budget, use_init, ki
     np.testing.assert_allclose(d, d_ref, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(d_ref).max()))
 
 
+@pytest.mark.parametrize("sigma,budget", [(1.0, 0), (0.7, 64), (1.0, 100)])
+def test_tiers_resume_bit_identical(dev, oracle_mod, sigma, budget):
+    """n > 64 runs in LDS tiers (storage for 63, 93, 129 active vertices); samples that outgrow a
+    tier are parked and resumed by the next launch.  192 samples at 128 bits reach every tier (the
+    test asserts that) and must still equal the one-pass CPU oracle bit for bit."""
+    from lvmhelpers import _native
+    B, n = 192, 128
+    x, init = _inputs(B, n, sigma, 4242 + budget)
+    ref = oracle_mod.sparsemap_fwd(x, init, budget, 300)
+    assert (ref["alen"] > 63).any() and (ref["alen"] <= 63).any()
+    if budget == 64:
+        assert (ref["alen"] > 93).any()
+    out = _native.sparsemap_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(init).to(dev), budget, 300)
+    alen = out["alen"].cpu().numpy()
+    assert np.array_equal(alen, ref["alen"])
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    assert np.array_equal(out["p"].cpu().numpy(), ref["p"])
+    inv = out["inv_a"].cpu().numpy()
+    for b in range(B):
+        m = alen[b]
+        assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
+
+
 def test_max_iter_is_respected(dev, oracle_mod):
     from lvmhelpers import _native
     x, init = _inputs(8, 64, 1.0, 9)
