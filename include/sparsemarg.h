@@ -136,6 +136,36 @@ int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_
 int smlvm_unpack_configs(const uint32_t* aset_bits, const int32_t* rows, const int32_t* cols,
                          float* out, int64_t N, int32_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Next rows after the hot path: the callers on the decoder side.
+ *
+ * Low-rank categorical negative log-likelihood without materialised logits.  Replaces, as a pair,
+ * CategoricalGenerator.forward's `self.out(X)` (experiments/bit_vector-vae/archs.py:26-29) and
+ * reconstruction_loss (experiments/bit_vector-vae/train.py:361-371):
+ *   logits[n,f,c] = b[c] + sum_r x[n,f,r] w[c,r];   loss[n] = sum_f (logsumexp_c logits - logits[n,f,y[n,f]])
+ *   x [N,F,R] fp32, w [C,R] fp32 (nn.Linear weight), b [C] fp32, y [N,F] labels in [0,C)
+ *   y_kind: 0 = uint8, 1 = int32, 2 = int64.   Limits: R <= 8, C <= 256.
+ *   fwd outputs: lse [N,F] fp32 (saved for the backward), nll [N,F] fp32, loss [N] fp32 (nullable)
+ *   bwd: gloss [N] = dL/dloss;  dx [N,F,R], dw [C,R], db [C] (each nullable); workspace of
+ *        smlvm_lowrank_ce_bwd_workspace_bytes bytes for the per-block dw/db partials.
+ */
+int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float* b, const void* y,
+                         int32_t y_kind, float* lse, float* nll, float* loss, int64_t N, int32_t F,
+                         int32_t C, int32_t R, void* stream);
+size_t smlvm_lowrank_ce_bwd_workspace_bytes(int64_t N, int32_t F, int32_t C, int32_t R);
+int smlvm_lowrank_ce_bwd(const float* x, const float* w, const float* b, const void* y,
+                         int32_t y_kind, const float* lse, const float* gloss, float* dx, float* dw,
+                         float* db, int64_t N, int32_t F, int32_t C, int32_t R, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* Segmented log-sum-exp over the compacted support lists.  Replaces the per-sample Python loop of
+ * compute_importance_sampling (experiments/bit_vector-vae/train.py:325-330:
+ * `torch.logsumexp(logp_x_given_z[torch.tensor(idxs) == k] + logp_z, dim=0)` for every k):
+ *   out[r] = log sum_{j in [row_offsets[r], row_offsets[r+1])} exp(v[j] + shift);  -inf for an
+ *   empty segment.  v [N] fp32, row_offsets [R+1] int64 (as produced by smlvm_support_offsets). */
+int smlvm_segmented_logsumexp(const float* v, const int64_t* row_offsets, float shift, float* out,
+                              int64_t R, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,8 @@ ABI_SYMBOLS = [
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
     "smlvm_sparsemap_bwd",
     "smlvm_unpack_configs",
+    "smlvm_lowrank_ce_fwd", "smlvm_lowrank_ce_bwd_workspace_bytes", "smlvm_lowrank_ce_bwd",
+    "smlvm_segmented_logsumexp",
 ]
 
 
@@ -47,6 +49,9 @@ def lib():
         L.smlvm_weighted_loss_reduce_workspace_bytes.argtypes = [ctypes.c_int64]
         L.smlvm_sparsemap_fwd_workspace_bytes.restype = ctypes.c_size_t
         L.smlvm_sparsemap_fwd_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+        L.smlvm_lowrank_ce_bwd_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_lowrank_ce_bwd_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32,
+                                                           ctypes.c_int32, ctypes.c_int32]
         if L.smlvm_abi_version() != 2:
             raise NativeError("libsparsemarg_hip.so: ABI version mismatch")
         _lib = L
@@ -257,4 +262,72 @@ def unpack_configs(aset_bits, rows, cols, n):
     with torch.cuda.device(aset_bits.device):
         _check(lib().smlvm_unpack_configs(_p(aset_bits), _p(rows), _p(cols), _p(out), _i64(N),
                                           _i32(n), _stream()), "smlvm_unpack_configs")
+    return out
+
+
+_Y_KINDS = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}
+
+
+def _labels(y, N, F):
+    if not y.is_cuda:
+        raise NativeError("labels: expected a GPU tensor (the hot path has no CPU fallback)")
+    if y.dtype not in _Y_KINDS:
+        y = y.to(torch.int64)
+    y = y.reshape(N, F).contiguous()
+    return y, _Y_KINDS[y.dtype]
+
+
+def lowrank_ce_fwd(x, w, b, y):
+    """x [N,F,R] f32, w [C,R] f32, b [C] f32, y [N,F] labels -> (loss [N], lse [N,F], nll [N,F])."""
+    x = _need_gpu(x, torch.float32, "x")
+    w = _need_gpu(w, torch.float32, "w")
+    b = _need_gpu(b, torch.float32, "b")
+    N, F, R = x.shape
+    C = w.shape[0]
+    if tuple(w.shape) != (C, R) or tuple(b.shape) != (C,):
+        raise ValueError("w must be [C,R] and b [C]")
+    y, kind = _labels(y, N, F)
+    dev = x.device
+    lse = torch.empty((N, F), dtype=torch.float32, device=dev)
+    nll = torch.empty((N, F), dtype=torch.float32, device=dev)
+    loss = torch.empty(N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_lowrank_ce_fwd(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(nll),
+                                          _p(loss), _i64(N), _i32(F), _i32(C), _i32(R), _stream()),
+               "smlvm_lowrank_ce_fwd")
+    return loss, lse, nll
+
+
+def lowrank_ce_bwd(x, w, b, y, lse, gloss, want_dx=True, want_dw=True):
+    x = _need_gpu(x, torch.float32, "x")
+    w = _need_gpu(w, torch.float32, "w")
+    b = _need_gpu(b, torch.float32, "b")
+    lse = _need_gpu(lse, torch.float32, "lse")
+    gloss = _need_gpu(gloss, torch.float32, "gloss")
+    N, F, R = x.shape
+    C = w.shape[0]
+    y, kind = _labels(y, N, F)
+    dev = x.device
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.zeros_like(w) if want_dw else None
+    db = torch.zeros_like(b) if want_dw else None
+    nbytes = lib().smlvm_lowrank_ce_bwd_workspace_bytes(N, F, C, R) if want_dw else 0
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_lowrank_ce_bwd(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(gloss),
+                                          _p(dx), _p(dw), _p(db), _i64(N), _i32(F), _i32(C), _i32(R),
+                                          _p(ws), ctypes.c_size_t(nbytes), _stream()),
+               "smlvm_lowrank_ce_bwd")
+    return dx, dw, db
+
+
+def segmented_logsumexp(v, row_offsets, shift=0.0):
+    """out[r] = logsumexp(v[row_offsets[r]:row_offsets[r+1]] + shift); -inf for empty segments."""
+    v = _need_gpu(v, torch.float32, "v")
+    row_offsets = _need_gpu(row_offsets, torch.int64, "row_offsets")
+    R = row_offsets.shape[0] - 1
+    out = torch.empty(R, dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _check(lib().smlvm_segmented_logsumexp(_p(v), _p(row_offsets), _f32(float(shift)), _p(out),
+                                               _i64(R), _stream()), "smlvm_segmented_logsumexp")
     return out

@@ -106,6 +106,31 @@ class _SparseMAP(torch.autograd.Function):
         return _native.sparsemap_bwd(dp.contiguous(), aset_bits, alen, inv_a, ctx.n), None, None, None
 
 
+class _LowRankCE(torch.autograd.Function):
+    """sum_f cross_entropy(x[n,f,:] @ w.T + b, y[n,f]) without the [N,F,C] logits
+    (experiments/bit_vector-vae/archs.py:26-29 + train.py:361-371)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, y):
+        loss, lse, _ = _native.lowrank_ce_fwd(x, w, b, y)
+        ctx.save_for_backward(x, w, b, y, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        x, w, b, y, lse = ctx.saved_tensors
+        dx, dw, db = _native.lowrank_ce_bwd(
+            x, w, b, y, lse, gloss.contiguous().to(torch.float32),
+            want_dx=ctx.needs_input_grad[0],
+            want_dw=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        return dx, dw, db, None
+
+
+def lowrank_categorical_nll(x, w, b, y):
+    """x [N,F,R], w [C,R], b [C], y [N,F] integer labels -> per-row loss [N]."""
+    return _LowRankCE.apply(x.contiguous(), w.contiguous(), b.contiguous(), y)
+
+
 def sparsemax(X, dim=-1):
     """entmax.sparsemax replacement: Euclidean projection of each slice along `dim` onto the simplex."""
     if dim < 0:

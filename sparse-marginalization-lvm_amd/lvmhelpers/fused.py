@@ -1,0 +1,73 @@
+"""Callers next to the hot path: decoder-side work over the compacted support.
+
+``CategoricalGenerator`` and ``reconstruction_loss`` are drop-ins for the pair in
+experiments/bit_vector-vae/archs.py:18-29 and experiments/bit_vector-vae/train.py:361-371 (same
+constructor, same ``state_dict`` keys ``gen.*``, ``out.weight``, ``out.bias``, same loss
+signature).  Together they compute the 784 x 256-way cross entropy of every support row without
+materialising the ``[N, 784, 256]`` logits (0.8 MB per row): the generator returns a
+``LowRankLogits`` handle and the loss hands it to the fused gfx950 kernels.  Any other consumer can
+call ``.materialize()`` to get the dense tensor the reference would have produced.
+
+``support_logsumexp`` replaces the per-sample Python loop of compute_importance_sampling
+(experiments/bit_vector-vae/train.py:325-330).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import _native
+from . import functional as F_
+
+
+class LowRankLogits:
+    """logits[n, f, c] = x[n, f, :] @ weight[c, :] + bias[c], kept factored."""
+
+    def __init__(self, x, weight, bias):
+        self.x, self.weight, self.bias = x, weight, bias
+
+    @property
+    def shape(self):
+        return torch.Size((self.x.shape[0], self.x.shape[1], self.weight.shape[0]))
+
+    def materialize(self):
+        return F.linear(self.x, self.weight, self.bias)
+
+
+class CategoricalGenerator(torch.nn.Module):
+    """experiments/bit_vector-vae/archs.py:18-29 with a lazy output layer."""
+
+    def __init__(self, gen, n_features, out_rank, n_classes):
+        super().__init__()
+        self.gen = gen
+        self.n_features = n_features
+        self.out_rank = out_rank
+        self.out = torch.nn.Linear(out_rank, n_classes)
+
+    def forward(self, Z, *args):
+        X = self.gen(Z)
+        X = X.reshape(-1, self.n_features, self.out_rank)
+        return LowRankLogits(X, self.out.weight, self.out.bias)
+
+
+def reconstruction_loss(inf_input, discrete_latent_z, _gen_input, gen_output, true_labels):
+    """experiments/bit_vector-vae/train.py:361-371; fused when ``gen_output`` is a LowRankLogits."""
+    if isinstance(gen_output, LowRankLogits):
+        n, f = gen_output.x.shape[0], gen_output.x.shape[1]
+        lv = F_.lowrank_categorical_nll(
+            gen_output.x, gen_output.weight, gen_output.bias, true_labels.reshape(n, f))
+        return lv, {}
+    Xhat_logits = gen_output.permute(0, 2, 1)
+    lv = F.cross_entropy(Xhat_logits, true_labels.to(dtype=torch.long), reduction="none")
+    return lv.sum(dim=1), {}
+
+
+def support_logsumexp(values, idxs, batch_size, shift=0.0):
+    """[logsumexp(values[idxs == k] + shift) for k in range(batch_size)] as one kernel.
+
+    ``idxs`` is the sorted sample index of every support entry (``log['idxs']`` of SparseMAPMarg,
+    a list or a tensor); ``values`` is ``-log['loss_output']``."""
+    dev = values.device
+    idx = torch.as_tensor(idxs, device=dev, dtype=torch.int64)
+    counts = torch.bincount(idx, minlength=batch_size)
+    off = torch.zeros(batch_size + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(counts, 0)
+    return _native.segmented_logsumexp(values.detach().to(torch.float32).contiguous(), off, shift)
