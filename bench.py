@@ -17,6 +17,8 @@ Extra objects on that line:
   sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
   sparsemap     batched active-set solver: samples/s and active-set iterations/s (N > 1: every rank
                 solves 1024 samples at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
+  train_steps   one optimisation step of each BASELINE.json model config on synthetic data (N > 1:
+                config 5 with the flat-bucket gradient all-reduce over RCCL)
   sparsemap_cpu_baseline  the fp64 C oracle of the solver timed on one host core, same workload
 """
 import argparse
@@ -195,6 +197,48 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
     return res
 
 
+def train_steps_bench(dev, world, rank):
+    """One optimisation step (forward, backward, gradient all-reduce when N > 1, Adam) of each
+    BASELINE.json model config on synthetic data of the experiment's shape (bench_models.py)."""
+    import bench_models as bm
+
+    def run(model, batch, B, steps=5, warm=2):
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        out = None
+        for _ in range(warm):
+            out = bm.train_step(model, opt, batch, distributed=world > 1)
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = bm.train_step(model, opt, batch, distributed=world > 1)
+        barrier(world)
+        ms = max_over_ranks((time.perf_counter() - t0) / steps * 1e3, world, dev)
+        sup = out["log"].get("support")
+        return {"ms_per_step": ms, "samples_per_s": B * world / (ms * 1e-3), "batch_per_gpu": B,
+                "mean_support": float(torch.as_tensor(sup, dtype=torch.float32).mean()) if sup is not None else None,
+                "loss": float(out["loss"])}
+
+    res = {}
+    if world == 1:
+        m, b = bm.make_ssvae(dev, 64)
+        res["cfg1_ssvae_marg_sparsemax_K10_b64"] = run(m, b, 64)
+        m, b = bm.make_signal_game(dev, 64)
+        res["cfg2_signal_game_marg_sparsemax_K256_b64"] = run(m, b, 64)
+        m, b = bm.make_bitvae(dev, 64, 32, "sparsemap")
+        res["cfg4_bitvae_sparsemap_32bits_b64"] = run(m, b, 64)
+        m, b = bm.make_bitvae(dev, 64, 32, "sparsemap", fused_decoder=False)
+        res["cfg4_bitvae_sparsemap_32bits_b64_dense_logits"] = run(m, b, 64)
+        m, b = bm.make_bitvae(dev, 64, 32, "topksparse")
+        res["cfg4_bitvae_topksparse_32bits_b64"] = run(m, b, 64)
+        del m, b
+    # cfg5: global batch 8192 over 8 GPUs = 1024 per rank, one flat-bucket RCCL all-reduce per step
+    m, b = bm.make_bitvae(dev, 1024, 128, "sparsemap", seed=0)
+    res["cfg5_bitvae_sparsemap_128bits_b1024_per_gpu"] = run(m, b, 1024, steps=3, warm=1)
+    res["cfg5_bitvae_sparsemap_128bits_b1024_per_gpu"]["grad_allreduce"] = (
+        f"1 bucket of {sum(p.numel() for p in m.parameters()) * 4 / 1e6:.1f} MB over {world} rank(s)")
+    return res
+
+
 def main():
     a = parse()
     world, rank, local = dist_setup(a.gpus)
@@ -272,6 +316,10 @@ def main():
         # cfg5: batch 8192 over 8 GPUs = 1024 samples per rank at 128 bits; samples sharded, no collective
         out["sparsemap"] = [sparsemap_bench(native, dev, 1024, 128, 0, 1.0, world=world, seed=77 + rank),
                             sparsemap_bench(native, dev, 1024, 128, 0, 3.0, world=world, seed=77 + rank)]
+    if not a.no_sweep:
+        torch.cuda.empty_cache()
+        ts = train_steps_bench(dev, world, rank)   # every rank takes part (collective inside)
+        out["train_steps"] = ts
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
         out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(1024, 128, 0, 1.0)
