@@ -15,6 +15,7 @@ Extra objects on that line:
                 launch stream inside the timed region) against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/, plain C, 1 thread) timed on this host on a bounded sample
   sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
+  compaction    support count / compaction / weighted reduction kernels vs their algorithmic bytes
   sparsemap     batched active-set solver: samples/s and active-set iterations/s (N > 1: every rank
                 solves 1024 samples at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
   train_steps   one optimisation step of each BASELINE.json model config on synthetic data (N > 1:
@@ -197,6 +198,43 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
     return res
 
 
+def compaction_bench(native, dev, R, K, sigma, reps=5):
+    """Kernel 2 on the probabilities of a forward pass: support_count, support_offsets,
+    support_compact and the weighted loss reduction, each against its algorithmic HBM bytes
+    (count 4KR read; compact 4KR + 12N + 8(R+1); reduce 12N read)."""
+    x, _ = gen(R, K, sigma, dev, 4321)
+    p, supp, nnz, _, _ = native.sparsemax_fwd(x, want_nnz=True)
+    del x
+
+    def timeit(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t_count = timeit(lambda: native.support_count(p))
+    t_off = timeit(lambda: native.support_offsets(nnz))
+    off, rows, cols, vals = native.support_compact(p, nnz)
+    N = int(rows.shape[0])
+    t_all = timeit(lambda: native.support_compact(p, nnz))       # offsets + one sync + compact
+    comps = torch.rand(N, device=dev) * 500
+    t_red = timeit(lambda: native.weighted_loss_reduce_fwd(vals, comps, off, 1.0 / R))
+    t_compact = max(t_all - t_off, 1e-6)
+    gb = lambda b, ms: b / (ms * 1e-3) / 1e9
+    return {"R": R, "K": K, "N": N,
+            "support_count": {"ms": t_count, "GBps": gb(4.0 * K * R, t_count)},
+            "support_offsets": {"ms": t_off},
+            "support_compact": {"ms": t_compact, "GBps": gb(4.0 * K * R + 12.0 * N + 8.0 * (R + 1), t_compact),
+                                "note": "offsets launch subtracted; includes the one host sync that sizes the lists"},
+            "weighted_loss_reduce_fwd": {"ms": t_red, "GBps": gb(12.0 * N, t_red)},
+            "frac_of_hbm_peak_count": gb(4.0 * K * R, t_count) / HBM_PEAK_GBS,
+            "frac_of_hbm_peak_compact": gb(4.0 * K * R + 12.0 * N + 8.0 * (R + 1), t_compact) / HBM_PEAK_GBS}
+
+
 def train_steps_bench(dev, world, rank):
     """One optimisation step (forward, backward, gradient all-reduce when N > 1, Adam) of each
     BASELINE.json model config on synthetic data of the experiment's shape (bench_models.py)."""
@@ -306,6 +344,9 @@ def main():
                               "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
                               "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
         out["sweep"] = sweep
+        out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
+                             compaction_bench(native, dev, 1 << 20, 256, a.sigma),
+                             compaction_bench(native, dev, 1 << 20, 256, 0.05)]
         out["sparsemap"] = [sparsemap_bench(native, dev, 64, 32, 0, 1.0),
                             sparsemap_bench(native, dev, 64, 32, 16, 1.0),
                             sparsemap_bench(native, dev, 1024, 128, 0, 1.0),
