@@ -147,17 +147,18 @@ __global__ __launch_bounds__(256) void support_compact_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < K4) v = p4[f];
             const float e[4] = {v.x, v.y, v.z, v.w};
-            const int mine = (e[0] > 0.0f) + (e[1] > 0.0f) + (e[2] > 0.0f) + (e[3] > 0.0f);
-            if (__ballot(mine != 0) == 0ull) continue;  // wave-uniform: nothing in these 1 KiB
-            // exclusive prefix of `mine` over lanes: column order is (lane, component)
-            int pre = mine;
+            // positives before this lane's first one, in (lane, component) order: four ballots +
+            // mbcnt instead of a shuffle scan
+            unsigned long long m[4];
+            int pre = 0, total = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                int o = __shfl_up(pre, d);
-                if (lane >= d) pre += o;
+            for (int c = 0; c < 4; ++c) {
+                m[c] = __ballot(e[c] > 0.0f);
+                pre += lanes_below(m[c]);
+                total += __popcll(m[c]);
             }
-            const int total = __shfl(pre, 63);
-            int64_t pos = out + (pre - mine);
+            if (total == 0) continue;  // wave-uniform: nothing in these 1 KiB
+            int64_t pos = out + pre;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (e[c] > 0.0f) {

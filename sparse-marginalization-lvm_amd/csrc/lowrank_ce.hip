@@ -21,15 +21,12 @@ namespace smlvm {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
-template <int R>
-__device__ __forceinline__ float logit(const float (&x)[R], const float* __restrict__ w,
-                                       const float* __restrict__ b, int c)
-{
-    float l = b[c];
-#pragma unroll
-    for (int r = 0; r < R; ++r) l = fmaf(x[r], w[c * R + r], l);
-    return l;
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 splat(float v) { f32x2 r = {v, v}; return r; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// raw v_exp_f32: arguments here are <= 0 (or bounded), results that underflow may flush to 0
+__device__ __forceinline__ float ex2(float v) { return __builtin_amdgcn_exp2f(v); }
 
 template <typename YT>
 __device__ __forceinline__ int label_at(const void* y, int64_t i)
@@ -37,36 +34,106 @@ __device__ __forceinline__ int label_at(const void* y, int64_t i)
     return (int)static_cast<const YT*>(y)[i];
 }
 
+// Every lane carries TWO (row, feature) pairs -- p and p + 256 of the block's 512 -- so that the
+// R FMAs of a logit and the shift run as v_pk_fma_f32 with the (wave-uniform) weight in a scalar
+// register; only the v_exp_f32 are per element.
+template <int R>
+__device__ __forceinline__ f32x2 logit2(const f32x2 (&x)[R], const float* __restrict__ w,
+                                        const float* __restrict__ b, int c)
+{
+    f32x2 l = splat(b[c]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) l = fma2(x[r], splat(w[c * R + r]), l);
+    return l;
+}
+
+// logit of one (divergent) class for one element: plain loads
+template <int R>
+__device__ __forceinline__ float logit_at(const f32x2 (&x)[R], int half, const float* __restrict__ w,
+                                          const float* __restrict__ b, int c)
+{
+    float l = b[c];
+#pragma unroll
+    for (int r = 0; r < R; ++r) l = fmaf(half ? x[r].y : x[r].x, w[c * R + r], l);
+    return l;
+}
+
+// exact two-pass log-sum-exp of one element (only when the bound-shifted sum underflowed)
+template <int R>
+__device__ float lse_exact(const f32x2 (&x)[R], int half, const float* __restrict__ w,
+                           const float* __restrict__ b, int C)
+{
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, logit_at<R>(x, half, w, b, c));
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += ex2((logit_at<R>(x, half, w, b, c) - mx) * kLog2e);
+    return fmaf(log2f(s), kLn2, mx);
+}
+
+constexpr int kPixPerBlock = 512;
+
 template <int R, typename YT>
 __global__ __launch_bounds__(256) void lowrank_ce_fwd_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
     const void* __restrict__ y, float* __restrict__ lse, float* __restrict__ nll, int64_t P, int C)
 {
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = p < P;
-    if (!live) p = P - 1;
-    float x[R];
+    // Upper bound of every logit of an element: max_c b_c + sum_r |x_r| max_c |W_cr|.  Shifting by
+    // it (instead of by the exact maximum) saves the whole max pass; the sum cannot overflow, and
+    // if the bound is so loose that it underflows the element is redone exactly.
+    __shared__ float red[4][R + 1];
+    {
+        const int c = threadIdx.x;
+        float v[R + 1];
 #pragma unroll
-    for (int r = 0; r < R; ++r) x[r] = X[p * R + r];
-    const int yy = label_at<YT>(y, p);
-    float mx = -INFINITY, ly = 0.0f;
+        for (int r = 0; r < R; ++r) v[r] = c < C ? fabsf(W[c * R + r]) : 0.0f;
+        v[R] = c < C ? b[c] : -INFINITY;
+#pragma unroll
+        for (int r = 0; r <= R; ++r) v[r] = group_reduce<64>(v[r], OpMaxF{});
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int r = 0; r <= R; ++r) red[threadIdx.x >> 6][r] = v[r];
+        }
+    }
+    __syncthreads();
+    float wabs[R + 1];
+#pragma unroll
+    for (int r = 0; r <= R; ++r)
+        wabs[r] = fmaxf(fmaxf(red[0][r], red[1][r]), fmaxf(red[2][r], red[3][r]));
+
+    int64_t p[2];
+    bool live[2];
+    p[0] = (int64_t)blockIdx.x * kPixPerBlock + threadIdx.x;
+    p[1] = p[0] + 256;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { live[h] = p[h] < P; if (!live[h]) p[h] = P - 1; }
+    f32x2 x[R];
+    f32x2 bound = splat(wabs[R]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        x[r].x = X[p[0] * R + r];
+        x[r].y = X[p[1] * R + r];
+        bound.x = fmaf(fabsf(x[r].x), wabs[r], bound.x);
+        bound.y = fmaf(fabsf(x[r].y), wabs[r], bound.y);
+    }
+    const f32x2 m2 = bound * kLog2e;
+    const f32x2 k2 = splat(kLog2e);
+    f32x2 s = splat(0.0f);
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
-        const float l = logit<R>(x, W, b, c);
-        mx = fmaxf(mx, l);
-        ly = (c == yy) ? l : ly;
+        const f32x2 t = fma2(logit2<R>(x, W, b, c), k2, -m2);
+        f32x2 e = {ex2(t.x), ex2(t.y)};
+        s += e;
     }
-    const float m2 = mx * kLog2e;
-    float s = 0.0f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) {
-        const float l = logit<R>(x, W, b, c);
-        s += exp2f(fmaf(l, kLog2e, -m2));
-    }
-    const float L = fmaf(log2f(s), kLn2, mx);
-    if (live) {
-        lse[p] = L;
-        nll[p] = L - ly;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float sh = h ? s.y : s.x, bh = h ? bound.y : bound.x;
+        float L = fmaf(log2f(sh), kLn2, bh);
+        if (!(sh > 1e-18f)) L = lse_exact<R>(x, h, W, b, C);   // also catches NaN
+        if (live[h]) {
+            const int yy = label_at<YT>(y, p[h]);
+            lse[p[h]] = L;
+            nll[p[h]] = L - logit_at<R>(x, h, W, b, yy);
+        }
     }
 }
 
@@ -84,99 +151,132 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
     if (lane == 0) out[row] = (float)acc;
 }
 
+// dX[p, r] = g (sum_c softmax_c W[c, r] - W[y, r])
 template <int R, typename YT>
 __global__ __launch_bounds__(256) void lowrank_ce_bwd_dx_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
     const void* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ gloss,
     float* __restrict__ dX, int64_t P, int F, int C)
 {
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = p < P;
-    if (!live) p = P - 1;
-    float x[R], dx[R];
+    int64_t p[2];
+    bool live[2];
+    p[0] = (int64_t)blockIdx.x * kPixPerBlock + threadIdx.x;
+    p[1] = p[0] + 256;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { x[r] = X[p * R + r]; dx[r] = 0.0f; }
-    const int yy = label_at<YT>(y, p);
-    const float g = gloss[p / F];
-    const float L2 = lse[p] * kLog2e;
+    for (int h = 0; h < 2; ++h) { live[h] = p[h] < P; if (!live[h]) p[h] = P - 1; }
+    f32x2 x[R], dx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        x[r].x = X[p[0] * R + r];
+        x[r].y = X[p[1] * R + r];
+        dx[r] = splat(0.0f);
+    }
+    f32x2 L2 = {lse[p[0]], lse[p[1]]};
+    L2 *= kLog2e;
+    const f32x2 k2 = splat(kLog2e);
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
-        const float l = logit<R>(x, W, b, c);
-        const float pr = exp2f(fmaf(l, kLog2e, -L2));
-        const float dl = pr - ((c == yy) ? 1.0f : 0.0f);
+        const f32x2 t = fma2(logit2<R>(x, W, b, c), k2, -L2);
+        const f32x2 pr = {ex2(t.x), ex2(t.y)};
 #pragma unroll
-        for (int r = 0; r < R; ++r) dx[r] = fmaf(dl, W[c * R + r], dx[r]);
+        for (int r = 0; r < R; ++r) dx[r] = fma2(pr, splat(W[c * R + r]), dx[r]);
     }
-    if (live) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) dX[p * R + r] = g * dx[r];
+    for (int h = 0; h < 2; ++h) {
+        if (!live[h]) continue;
+        const int yy = label_at<YT>(y, p[h]);
+        const float g = gloss[p[h] / F];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            dX[p[h] * R + r] = g * ((h ? dx[r].y : dx[r].x) - W[yy * R + r]);
     }
 }
 
-constexpr int kDwTile = 64;       // (row, feature) pairs staged per step
+constexpr int kDwTile = 64;       // (row, feature) pairs staged per step (even)
 constexpr int kDwMaxBlocks = 2048;
 
+// dW[c, r] = sum_p g_p (softmax_pc - [c == y_p]) x_pr, db[c] likewise with x = 1: thread = class,
+// (row, feature) pairs two at a time from an LDS tile stored [r][pair] so a pair is one ds_read_b64.
 template <int R, typename YT>
 __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
     const void* __restrict__ y, const float* __restrict__ lse, const float* __restrict__ gloss,
     float* __restrict__ partial, int64_t P, int F, int C)
 {
-    __shared__ float xs[kDwTile * R];
-    __shared__ float ls[kDwTile];
-    __shared__ float gs[kDwTile];
-    __shared__ int ys[kDwTile];
+    __shared__ __align__(8) float xs[R * kDwTile];
+    __shared__ __align__(8) float ls[kDwTile];
+    __shared__ __align__(8) float gs[kDwTile];
+    __shared__ __align__(8) int ys[kDwTile];
     const int c = threadIdx.x;
     const bool mine = c < C;
-    float w[R], acc[R + 1];
+    float w[R];
+    f32x2 acc[R + 1];
     float bc = 0.0f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) { w[r] = mine ? W[c * R + r] : 0.0f; acc[r] = 0.0f; }
-    acc[R] = 0.0f;
+    for (int r = 0; r < R; ++r) { w[r] = mine ? W[c * R + r] : 0.0f; acc[r] = splat(0.0f); }
+    acc[R] = splat(0.0f);
     if (mine) bc = b[c];
+    const f32x2 k2 = splat(kLog2e);
     const int64_t tiles = (P + kDwTile - 1) / kDwTile;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t p0 = t * kDwTile;
         const int cnt = (int)((P - p0 < kDwTile) ? (P - p0) : kDwTile);
         __syncthreads();  // previous tile fully consumed
-        for (int i = threadIdx.x; i < cnt * R; i += 256) xs[i] = X[p0 * R + i];
-        if (threadIdx.x < cnt) {
-            const int64_t p = p0 + threadIdx.x;
+        for (int i = threadIdx.x; i < kDwTile * R; i += 256) {
+            const int pix = i / R, r = i - pix * R;
+            xs[r * kDwTile + pix] = pix < cnt ? X[p0 * R + i] : 0.0f;
+        }
+        if (threadIdx.x < kDwTile) {
+            const bool ok = threadIdx.x < cnt;
+            const int64_t p = ok ? p0 + threadIdx.x : p0;
             ls[threadIdx.x] = lse[p] * kLog2e;
-            gs[threadIdx.x] = gloss[p / F];
-            ys[threadIdx.x] = label_at<YT>(y, p);
+            gs[threadIdx.x] = ok ? gloss[p / F] : 0.0f;   // padding contributes nothing
+            ys[threadIdx.x] = ok ? label_at<YT>(y, p) : -1;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < cnt; ++i) {
-            float l = bc;
+#pragma unroll 2
+        for (int i = 0; i < kDwTile; i += 2) {
+            f32x2 xr[R];
+            f32x2 l = splat(bc);
 #pragma unroll
-            for (int r = 0; r < R; ++r) l = fmaf(xs[i * R + r], w[r], l);
-            const float pr = exp2f(fmaf(l, kLog2e, -ls[i]));
-            const float dl = gs[i] * (pr - ((c == ys[i]) ? 1.0f : 0.0f));
+            for (int r = 0; r < R; ++r) {
+                xr[r] = *reinterpret_cast<const f32x2*>(&xs[r * kDwTile + i]);
+                l = fma2(xr[r], splat(w[r]), l);
+            }
+            const f32x2 lz = *reinterpret_cast<const f32x2*>(&ls[i]);
+            const f32x2 g = *reinterpret_cast<const f32x2*>(&gs[i]);
+            const int y0 = ys[i], y1 = ys[i + 1];
+            const f32x2 tt = fma2(l, k2, -lz);
+            const f32x2 pr = {ex2(tt.x), ex2(tt.y)};
+            f32x2 hot = {(c == y0) ? 1.0f : 0.0f, (c == y1) ? 1.0f : 0.0f};
+            const f32x2 dl = g * (pr - hot);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fmaf(dl, xs[i * R + r], acc[r]);
+            for (int r = 0; r < R; ++r) acc[r] = fma2(dl, xr[r], acc[r]);
             acc[R] += dl;
         }
     }
     if (mine) {
         float* o = partial + ((int64_t)blockIdx.x * C + c) * (R + 1);
 #pragma unroll
-        for (int r = 0; r <= R; ++r) o[r] = acc[r];
+        for (int r = 0; r <= R; ++r) o[r] = acc[r].x + acc[r].y;
     }
 }
 
-// dW[c, r] / db[c] = sum over blocks of the partials, in block order, fp64
+// dW[c, r] / db[c] = sum over blocks of the partials: one wave per output, lanes stride over the
+// blocks in fp64, fixed DPP tree at the end (deterministic)
 __global__ __launch_bounds__(256) void lowrank_ce_reduce_kernel(const float* __restrict__ partial,
                                                                 int nblk, int C, int R,
                                                                 float* __restrict__ dW,
                                                                 float* __restrict__ db)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int per = C * (R + 1);
-    if (j >= per) return;
+    if (j >= per) return;  // whole wave
     double acc = 0.0;
-    for (int k = 0; k < nblk; ++k) acc += (double)partial[(int64_t)k * per + j];
+    for (int k = lane; k < nblk; k += 64) acc += (double)partial[(int64_t)k * per + j];
+    acc = group_reduce<64>(acc, OpSum{});
+    if (lane != 0) return;
     const int c = j / (R + 1), r = j - c * (R + 1);
     if (r < R) { if (dW) dW[c * R + r] = (float)acc; }
     else if (db) db[c] = (float)acc;
@@ -228,7 +328,7 @@ extern "C" int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float*
     if (N == 0) return SMLVM_OK;
     if (!x || !w || !b || !y || !lse || !nll) return SMLVM_ERR_INVALID;
     const int64_t P = N * F;
-    const unsigned grid = (unsigned)((P + 255) / 256);
+    const unsigned grid = (unsigned)((P + kPixPerBlock - 1) / kPixPerBlock);
     hipStream_t st = (hipStream_t)stream;
     SMLVM_LR_DISPATCH_R(R, SMLVM_LR_DISPATCH_Y(y_kind,
         hipLaunchKernelGGL((lowrank_ce_fwd_kernel<RR, YY>), dim3(grid), dim3(256), 0, st, x, w, b, y,
@@ -258,7 +358,7 @@ extern "C" int smlvm_lowrank_ce_bwd(const float* x, const float* w, const float*
     const int64_t P = N * F;
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        const unsigned grid = (unsigned)((P + 255) / 256);
+        const unsigned grid = (unsigned)((P + kPixPerBlock - 1) / kPixPerBlock);
         SMLVM_LR_DISPATCH_R(R, SMLVM_LR_DISPATCH_Y(y_kind,
             hipLaunchKernelGGL((lowrank_ce_bwd_dx_kernel<RR, YY>), dim3(grid), dim3(256), 0, st, x, w,
                                b, y, lse, gloss, dx, P, F, C)));
@@ -276,7 +376,7 @@ extern "C" int smlvm_lowrank_ce_bwd(const float* x, const float* w, const float*
         int rc2 = check_launch();
         if (rc2 != SMLVM_OK) return rc2;
         const int per = C * (R + 1);
-        hipLaunchKernelGGL(lowrank_ce_reduce_kernel, dim3((per + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL(lowrank_ce_reduce_kernel, dim3((per + 3) / 4), dim3(256), 0, st,
                            partial, nblk, C, R, dw, db);
         rc2 = check_launch();
         if (rc2 != SMLVM_OK) return rc2;
