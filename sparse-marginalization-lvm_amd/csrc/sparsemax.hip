@@ -15,7 +15,8 @@
 //     are re-tested with exactly those fp32 expressions, from an fp64 sum of the candidate set,
 //     and the set is moved rank by rank until the test flips exactly at its edge;
 //   * epilogue fused: p = max(z - tau, 0), support size, #{p>0}, optional entropy.
-// Backward: dx = [p != 0] * (dy - sum(dy[p != 0]) / supp_size), fp64 row sum.
+// Backward: dx = [p != 0] * (dy - sum(dy[p != 0]) / supp_size), fp64 row sum; rows with a small
+// support gather dy at the support instead of streaming the row (12K -> ~8K bytes of traffic).
 #include "common.hpp"
 
 #include <float.h>
@@ -486,11 +487,54 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
     }
 }
 
+// The backward needs dy only where p != 0.  When the support is small the row of dy is not
+// streamed at all: each non-zero of p fetches its own element (one 64/128-byte sector per support
+// element instead of 4K bytes per row).  `nz` must be wave-uniformly known to be small by the
+// caller; per register the ballot skips the load unless some lane has a non-zero there.
+constexpr int kGatherMaxSupport = 96;   // ~ where 128-byte sectors per element reach the 4K-byte row
+
+// a[]: in = the row of p, out = the row of dx.  The gathered dy values replace the non-zeros of p
+// in place (one register array; a 64-bit per-lane mask remembers where they are), zeros stay
+// zeros, so the fp64 row sum adds the same numbers in the same order as the streaming path.
+template <int E, bool VEC, class Red>
+__device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, int gl, int GT,
+                                               float (&a)[E], int s, Red& red)
+{
+    static_assert(E <= 64, "one mask bit per register");
+    // mask bits with vector ALU only (no lane masks kept alive in scalar registers)
+    uint32_t mlo = 0u, mhi = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        uint32_t t = __builtin_bit_cast(uint32_t, a[e]) & 0x7fffffffu;
+        t = t < 1u ? t : 1u;
+        if (e < 32) mlo |= t << e; else mhi |= t << (e - 32);
+    }
+    asm volatile("" : "+v"(mlo), "+v"(mhi));
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool nzero = ((e < 32 ? mlo >> e : mhi >> (e - 32)) & 1u) != 0u;
+        if (__ballot(nzero) != 0ull) {   // wave-uniform
+            const int col = VEC ? (((e >> 2) * GT + gl) * 4 + (e & 3)) : (e * GT + gl);
+            if (nzero) a[e] = dyrow[col];
+        }
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc += (double)a[e];
+    acc = red.sum(acc);
+    const float v = (float)acc / (float)s;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool nzero = ((e < 32 ? mlo >> e : mhi >> (e - 32)) & 1u) != 0u;
+        a[e] = nzero ? (a[e] - v) : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------- kernels
 constexpr int kWavesPerBlock = 4;
 // waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
 constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
-constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 4; }
+constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 
 // EXTRA: any of the optional outputs (nnz, tau, entropy) requested.
 template <int G, int E, bool VEC, bool FULL, bool EXTRA>
@@ -577,12 +621,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
     const bool live = row < R;
     if (!live) row = R - 1;
-    float g[E], pv[E];
-    load_row<E, VEC, FULL>(p + row * K, K, gl, G, pv, 0.0f);
-    load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+    const int s = supp[row];
     WaveRed<G> red;
-    bwd_row(g, pv, supp[row], red);
-    if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
+    if (__ballot(s > kGatherMaxSupport) == 0ull) {   // every row of this wave has a small support
+        float a[E];
+        load_row<E, VEC, FULL>(p + row * K, K, gl, G, a, 0.0f);
+        bwd_row_gather<E, VEC>(dy + row * K, gl, G, a, s, red);
+        if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+    } else {
+        float g[E], pv[E];
+        load_row<E, VEC, FULL>(p + row * K, K, gl, G, pv, 0.0f);
+        load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+        bwd_row(g, pv, s, red);
+        if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
+    }
 }
 
 template <int NW, int E, bool VEC, bool FULL>
@@ -592,12 +644,20 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_bwd_block_kernel(
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
-        float g[E], pv[E];
-        load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, pv, 0.0f);
-        load_row<E, VEC, FULL>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
+        const int s = supp[row];   // block-uniform
         BlockRed<NW> red(lds);
-        bwd_row(g, pv, supp[row], red);
-        store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, g);
+        if (s <= kGatherMaxSupport) {
+            float a[E];
+            load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, a, 0.0f);
+            bwd_row_gather<E, VEC>(dy + row * K, threadIdx.x, 64 * NW, a, s, red);
+            store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, a);
+        } else {
+            float g[E], pv[E];
+            load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, pv, 0.0f);
+            load_row<E, VEC, FULL>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
+            bwd_row(g, pv, s, red);
+            store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, g);
+        }
         __syncthreads();
     }
 }

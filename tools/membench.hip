@@ -114,6 +114,26 @@ __global__ __launch_bounds__(BS) void k_2r1w_btile(const float4* __restrict__ a,
     }
 }
 
+// XCD-aware: workgroup b runs on XCD b % 8; give each XCD one contiguous eighth of the tensor
+template <int U, bool NT, int BS, int CH>
+__global__ __launch_bounds__(BS) void k_copy_tile_xcd(const float4* __restrict__ a, float4* __restrict__ o, size_t n)
+{
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    unsigned lb;
+    if (CH == 0) lb = (b % 8) * (nb / 8) + b / 8;                     // whole eighths
+    else { const unsigned g = b / (8 * CH), r = b % (8 * CH); lb = g * 8 * CH + (r % 8) * CH + r / 8; }  // chunks of CH blocks
+    size_t wave = ((size_t)lb * BS + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* s4 = reinterpret_cast<const f4*>(a + wave * (64 * U));
+    f4* d4 = reinterpret_cast<f4*>(o + wave * (64 * U));
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(s4 + u * 64 + lane) : s4[u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], d4 + u * 64 + lane); else d4[u * 64 + lane] = v[u]; }
+}
+
 template <class F>
 static double timeit(F f, int reps = 10)
 {
@@ -137,6 +157,16 @@ int main(int argc, char** argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
     double t;
+    if (argc > 2) {
+#define XC(U, NT, BS, CH) t = timeit([&] { k_copy_tile_xcd<U, NT, BS, CH><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(a, o, n); }); \
+    printf("copy tile xcd-remap U=%d nt=%d BS=%d chunk=%d: %.2f TB/s\n", U, (int)NT, BS, CH, 2.0 * bytes / t / 1e12);
+        XC(16, true, 256, 0) XC(16, true, 256, 1) XC(16, true, 256, 2) XC(16, true, 256, 4) XC(16, true, 256, 16) XC(16, true, 256, 64)
+        XC(16, true, 64, 0) XC(16, true, 64, 4) XC(16, true, 64, 16) XC(16, true, 512, 0) XC(16, true, 512, 4) XC(16, true, 1024, 0)
+        XC(4, true, 256, 0) XC(4, true, 256, 4) XC(4, true, 256, 16) XC(1, true, 256, 0) XC(1, true, 256, 16) XC(16, false, 256, 0) XC(16, false, 256, 4)
+        t = timeit([&] { k_copy_tile_nt<16, true, true, 256><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+        printf("copy tile U=16 nt-both (no remap): %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+        return 0;
+    }
     for (int g : {2048, 8192, 65536}) {
         t = timeit([&] { k_copy<<<g, 256>>>(a, o, n); });
         printf("copy grid-stride grid=%d: %.2f TB/s\n", g, 2.0 * bytes / t / 1e12);
