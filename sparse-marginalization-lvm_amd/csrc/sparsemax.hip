@@ -532,6 +532,17 @@ __device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, 
 
 // ------------------------------------------------------------------------------- kernels
 constexpr int kWavesPerBlock = 4;
+
+// Workgroup b is dispatched to XCD b % 8: hand each XCD one contiguous eighth of the rows, so the
+// lines one XCD's L2 and memory channels see are neighbours (+3 % on a plain copy of this shape,
+// +7 % on the K = 4096 forward; only for one-row-per-wave tiles, small rows lose a little).
+template <bool REMAP>
+__device__ __forceinline__ unsigned xcd_block()
+{
+    if constexpr (!REMAP) return blockIdx.x;
+    const unsigned nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
+    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+}
 // waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
 constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
 constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
-    int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
-    int64_t row = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
     const bool live = row < R;
     if (!live) row = R - 1;
     const int s = supp[row];
