@@ -54,7 +54,8 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("SMLVM_BENCH_FORCE_DIST") == "1":
+        # (the env switch lets a 1-GPU box rehearse the RCCL code path with a single rank)
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -63,15 +64,20 @@ def dist_setup(n_gpus):
     return world, rank, local
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def barrier(world):
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world, dev):
-    if world == 1:
+    if not _dist_on():
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device=dev)
@@ -191,7 +197,7 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
            "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
            "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
            "converged_frac": float((out["status"] != 1).float().mean().item())}
-    if world > 1:  # whole-job figures: every rank solves its own B samples, slowest rank counts
+    if _dist_on():  # whole-job figures: every rank solves its own B samples, slowest rank counts
         ms_max = max_over_ranks(ms, world, dev)
         res.update({"n_gpus": world, "B_total": B * world, "fwd_ms_max_over_ranks": ms_max,
                     "samples_per_s": B * world / (ms_max * 1e-3)})
@@ -244,11 +250,11 @@ def train_steps_bench(dev, world, rank):
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         out = None
         for _ in range(warm):
-            out = bm.train_step(model, opt, batch, distributed=world > 1)
+            out = bm.train_step(model, opt, batch, distributed=_dist_on())
         barrier(world)
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = bm.train_step(model, opt, batch, distributed=world > 1)
+            out = bm.train_step(model, opt, batch, distributed=_dist_on())
         barrier(world)
         ms = max_over_ranks((time.perf_counter() - t0) / steps * 1e3, world, dev)
         sup = out["log"].get("support")
@@ -257,7 +263,7 @@ def train_steps_bench(dev, world, rank):
                 "loss": float(out["loss"])}
 
     res = {}
-    if world == 1:
+    if not _dist_on():
         m, b = bm.make_ssvae(dev, 64)
         res["cfg1_ssvae_marg_sparsemax_K10_b64"] = run(m, b, 64)
         m, b = bm.make_signal_game(dev, 64)
@@ -280,7 +286,7 @@ def train_steps_bench(dev, world, rank):
 def main():
     a = parse()
     world, rank, local = dist_setup(a.gpus)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if _dist_on() else 0)
     from lvmhelpers import _native as native
     native.lib()
 
@@ -339,7 +345,7 @@ def main():
         "kernels": kern,
     }
 
-    if rank == 0 and world == 1 and not a.no_sweep:
+    if rank == 0 and not _dist_on() and not a.no_sweep:
         sweep = {}
         for K, R, chunks in ((256, 1 << 20, 1), (65536, 1 << 15, 32)):
             xs, dys = gen(R, K, a.sigma, dev, 99)
@@ -360,7 +366,7 @@ def main():
                             sparsemap_bench(native, dev, 1024, 128, 64, 1.0),
                             sparsemap_bench(native, dev, 1024, 128, 0, 3.0),
                             sparsemap_bench(native, dev, 8192, 128, 0, 1.0)]
-    if world > 1 and not a.no_sweep:
+    if _dist_on() and not a.no_sweep:
         # cfg5: batch 8192 over 8 GPUs = 1024 samples per rank at 128 bits; samples sharded, no collective
         out["sparsemap"] = [sparsemap_bench(native, dev, 1024, 128, 0, 1.0, world=world, seed=77 + rank),
                             sparsemap_bench(native, dev, 1024, 128, 0, 3.0, world=world, seed=77 + rank)]
@@ -368,12 +374,12 @@ def main():
         torch.cuda.empty_cache()
         ts = train_steps_bench(dev, world, rank)   # every rank takes part (collective inside)
         out["train_steps"] = ts
-    if rank == 0 and world == 1 and not a.no_cpu:
+    if rank == 0 and not _dist_on() and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
         out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(1024, 128, 0, 1.0)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.destroy_process_group()
 
