@@ -59,12 +59,12 @@ def _elbo_loss(image, z, _vae_input, out, labels):
     return bce + kl, {'acc': (z == labels).float()}
 
 
-def make_ssvae(dev, batch=64, seed=0):
+def make_ssvae(dev, batch=64, seed=0, compact=False):
     torch.manual_seed(seed)
     classifier = _mlp([784, 256, 256, 256, 10])
     model = Marginalizer(ExplicitWrapper(classifier, normalizer='sparsemax'),
                          DeterministicWrapper(_GaussianVAE()), _elbo_loss,
-                         encoder_entropy_coeff=1.0).to(dev)
+                         encoder_entropy_coeff=1.0, compact=compact).to(dev)
     image = torch.rand(batch, 784, device=dev)
     labels = torch.randint(0, 10, (batch,), device=dev)
     return model, (image, image, labels)
@@ -104,11 +104,13 @@ def _game_loss(_sender_input, message, _receiver_input, receiver_output, labels)
     return nll, {'acc': (receiver_output.argmax(1) == labels).float()}
 
 
-def make_signal_game(dev, batch=64, game_size=16, feat=4096, vocab=256, seed=0):
+def make_signal_game(dev, batch=64, game_size=16, feat=4096, vocab=256, seed=0, compact=False):
     torch.manual_seed(seed)
+    # receiver input is [game_size, B, feat]: the batch axis is 1; the sender input is not needed
+    # by the loss, so it is not gathered (batch_dims[0] = None)
     model = Marginalizer(ExplicitWrapper(_Sender(feat, 256, 512, vocab), normalizer='sparsemax'),
                          DeterministicWrapper(_Receiver(game_size, feat, 256, vocab)), _game_loss,
-                         encoder_entropy_coeff=0.1).to(dev)
+                         encoder_entropy_coeff=0.1, compact=compact, batch_dims=(None, 1)).to(dev)
     x = torch.randn(game_size, batch, feat, device=dev)       # sender input: x[0] is the target
     labels = torch.randint(0, game_size, (batch,), device=dev)
     recv = x.clone()                                            # receiver sees it at slot labels[b]

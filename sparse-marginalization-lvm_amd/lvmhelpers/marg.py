@@ -4,9 +4,12 @@ Same public surface as the reference (marg.py:6,31-54,57-132); the arithmetic of
 sparsemax forward/backward, entropy, the probability-weighted loss reduction -- runs in the
 gfx950 kernels behind ``include/sparsemarg.h``.
 """
+import os
+
 import torch
 import torch.nn as nn
 
+from . import _native
 from . import functional as F_
 
 
@@ -56,6 +59,14 @@ class Marginalizer(torch.nn.Module):
     The decoder is run on the full batch once per latent value that is live for at least one row,
     exactly like the reference, but the live set is read back with ONE host sync instead of one per
     category (marg.py:87), and ``sum_z p(z|x) * loss_z`` is the fused weighted-reduction kernel.
+
+    ``compact=True`` (keyword only here; or ``LVMHELPERS_COMPACT=1`` in the environment for
+    unchanged scripts) is the support-only mode the compaction kernel exists for: the (row, latent)
+    pairs with p > 0 are listed, the inputs are gathered by row along ``batch_dims = (encoder_input
+    dim, decoder_input dim)`` (``None`` = hand the tensor over as it is) and the decoder and the loss
+    run ONCE over N = sum_b |supp_b| rows instead of B rows for each of the |union of supports|
+    live columns.  Loss, gradients and every log value are the same sums in a different order; a
+    decoder that draws random numbers (the SSVAE's) consumes the generator differently.
     """
 
     def __init__(
@@ -64,17 +75,54 @@ class Marginalizer(torch.nn.Module):
             decoder,
             loss_fun,
             encoder_entropy_coeff=0.0,
-            decoder_entropy_coeff=0.0):
+            decoder_entropy_coeff=0.0,
+            *,
+            compact=None,
+            batch_dims=(0, 0)):
         super().__init__()
         self.encoder = encoder
         self.decoder = decoder
         self.loss = loss_fun
         self.encoder_entropy_coeff = encoder_entropy_coeff
         self.decoder_entropy_coeff = decoder_entropy_coeff
+        self.compact = (os.environ.get("LVMHELPERS_COMPACT") == "1") if compact is None else bool(compact)
+        self.batch_dims = batch_dims
+
+    def _forward_compact(self, encoder_input, decoder_input, labels, discrete_latent_z,
+                         encoder_probs, encoder_entropy):
+        batch_size, latent_size = encoder_probs.shape
+        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False)
+        rows_l, cols_l = rows.long(), cols.long()
+        if rows_l.numel() == 0:
+            raise RuntimeError("Marginalizer: the encoder distribution has no live category")
+
+        def take(t, dim):
+            return t if dim is None else t.index_select(dim, rows_l)
+
+        encoder_input_sel = take(encoder_input, self.batch_dims[0])
+        decoder_input_sel = take(decoder_input, self.batch_dims[1])
+        decoder_output = self.decoder(cols_l, decoder_input_sel)
+        loss_n, logs = self.loss(
+            encoder_input_sel, discrete_latent_z[rows_l], decoder_input_sel, decoder_output,
+            labels[rows_l])
+        probs_sel = encoder_probs[rows_l, cols_l]
+        loss_mean = F_.weighted_loss(probs_sel, loss_n.to(encoder_probs.dtype), 1.0 / batch_size)
+        for k, v in logs.items():
+            if hasattr(v, 'mean'):   # sum_z (p[:, z] * v_z).mean() of the reference, marg.py:107-113
+                logs[k] = (probs_sel * v).sum() / batch_size
+        entropy_loss = -(encoder_entropy.mean() * self.encoder_entropy_coeff)
+        logs['loss'] = loss_mean
+        logs['encoder_entropy'] = encoder_entropy.mean()
+        logs['support'] = (encoder_probs != 0).sum(-1).to(torch.float).mean()
+        logs['distr'] = encoder_probs
+        return {'loss': loss_mean + entropy_loss.mean(), 'log': logs}
 
     def forward(self, encoder_input, decoder_input, labels):
         discrete_latent_z, encoder_probs, encoder_entropy = self.encoder(encoder_input)
         batch_size, latent_size = encoder_probs.shape
+        if self.compact:
+            return self._forward_compact(encoder_input, decoder_input, labels, discrete_latent_z,
+                                         encoder_probs, encoder_entropy)
         entropy_loss = -(encoder_entropy.mean() * self.encoder_entropy_coeff)
 
         # columns whose probability mass is non-zero for some row (marg.py:87), one sync

@@ -138,3 +138,36 @@ def test_entmax_shim(dev, oracle_mod):
     assert np.allclose(xt.grad.cpu().numpy(), g_ref, atol=1e-6)
     p15 = entmax.entmax15(torch.from_numpy(x).to(dev), dim=-1)
     assert torch.allclose(p15.sum(-1), torch.ones(64, device=dev), atol=1e-5)
+
+
+@pytest.mark.parametrize("K,coeff", [(10, 1.0), (256, 0.1)])
+def test_marginalizer_compact_equals_dense(dev, K, coeff):
+    """Support-only mode (one decoder call over the compacted (row, latent) pairs) gives the same
+    loss, logs and gradients as the reference's column loop (marg.py:86-126)."""
+    from lvmhelpers.marg import ExplicitWrapper, Marginalizer
+    from lvmhelpers.utils import DeterministicWrapper
+    from toy_models import CatDecoder, ScoreTable, cat_loss, _seeded
+    B, D = 32, 12
+    res = []
+    for compact in (False, True):
+        torch.manual_seed(0)
+        enc = ScoreTable(B, K, scale=1.0)
+        with torch.no_grad():
+            enc.table.copy_(torch.randn(B, K, generator=torch.Generator().manual_seed(5)) * 1.5)
+        dec = _seeded(CatDecoder(K, D), 11)
+        enc, dec = enc.to(dev), dec.to(dev)
+        x = torch.randn(B, D, generator=torch.Generator().manual_seed(6)).to(dev)
+        labels = torch.randint(0, K, (B,), generator=torch.Generator().manual_seed(7)).to(dev)
+        model = Marginalizer(ExplicitWrapper(enc, normalizer="sparsemax"), DeterministicWrapper(dec),
+                             cat_loss, encoder_entropy_coeff=coeff, compact=compact)
+        out = model(x, x, labels)
+        out["loss"].backward()
+        res.append((out, [p.grad.clone() for p in list(enc.parameters()) + list(dec.parameters())]))
+    (o0, g0), (o1, g1) = res
+    assert sorted(o0["log"].keys()) == sorted(o1["log"].keys())
+    assert abs(float(o0["loss"]) - float(o1["loss"])) <= 2e-6 * max(1.0, abs(float(o0["loss"])))
+    for k in ("loss", "acc", "encoder_entropy", "support"):
+        assert abs(float(o0["log"][k]) - float(o1["log"][k])) <= 2e-6 * max(1.0, abs(float(o0["log"][k])))
+    assert torch.equal(o0["log"]["distr"], o1["log"]["distr"])
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
