@@ -7,8 +7,9 @@
 // so forward and backward recompute them from X (20 B per feature) and keep only the per-feature
 // log-sum-exp.  Compute bound (fp32 VALU FMA + v_exp_f32); HBM traffic is ~32 B per (row, feature).
 //
-//   fwd   lane = one (row, feature): max pass + exp pass over the C classes; W and b are read with
-//         wave-uniform addresses (scalar loads); then a per-row sum.
+//   fwd   lane = two (row, feature) pairs: one exp pass over the C classes, shifted by an upper
+//         bound of the logits (exact two-pass redo if that underflows); W and b are read with
+//         wave-uniform addresses (scalar loads) and feed v_pk_fma_f32; then a per-row sum.
 //   bwd   dX: lane = one (row, feature), softmax from the saved lse, dX = g (softmax - onehot) W
 //         dW, db: thread = one class, loops over (row, feature) tiles staged in LDS; per-block
 //         partials, then a deterministic fp64 reduction over blocks (no float atomics).

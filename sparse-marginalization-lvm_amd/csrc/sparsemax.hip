@@ -402,6 +402,61 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* ca
     tau_out = tau_f;
 }
 
+// Same idea for rows held by a lane group of G < 64 lanes (K <= 512, several rows per wave): each
+// group compacts its own candidates into its slice of the wave's LDS list (ballots are wave wide;
+// a lane looks at its group's bits only) and the threshold search runs on Q values per lane
+// instead of E.  If any row of the wave has more candidates than its slice holds, the whole wave
+// takes the full-width search.
+template <int E, int G>
+__device__ __forceinline__ void sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand,
+                                                    int& supp, float& tau_out)
+{
+    static_assert(G < 64, "lane groups inside one wave");
+    constexpr int Q = (G >= 16) ? 2 : 32 / G;   // candidates per lane: capacity G*Q = 32, 32, 64
+    constexpr int CAP = G * Q;
+    float mx = z[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    mx = red.max(mx);
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] -= mx;
+
+    const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G;
+    const unsigned group_bits = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+    const unsigned below_bits = (1u << gl) - 1u;
+    float* list = cand + grp * CAP;
+    int base = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = z[e] > -1.0f;
+        const unsigned long long m = __ballot(in);
+        if (m != 0ull) {  // wave-uniform
+            const unsigned mine = (unsigned)(m >> (grp * G)) & group_bits;
+            const int off = base + __popc(mine & below_bits);
+            if (in && off < CAP) list[off] = z[e];
+            base += __popc(mine);
+        }
+    }
+    int s_final = 1;
+    double S_final = 0.0;
+    if (__ballot(base > CAP) == 0ull) {
+        float c[Q];
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c[q] = (gl + G * q < base) ? list[gl + G * q] : -INFINITY;
+        wave_lds_sync();
+        solve_core(c, red, s_final, S_final);
+    } else {
+        solve_core(z, red, s_final, S_final);
+    }
+    const float c_s = (float)S_final - 1.0f;
+    const float tau_f = c_s / (float)s_final;
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = fmaxf(z[e] - tau_f, 0.0f);
+    supp = s_final;
+    tau_out = tau_f;
+}
+
 template <int E, class Red>
 __device__ __forceinline__ void row_epilogue(const float (&p)[E], Red& red, bool want_nnz,
                                              bool want_ent, int& nnz, float& ent)
@@ -560,13 +615,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
-    __shared__ float cand[CAND ? kWavesPerBlock * kCandCap : 1];
+    constexpr bool GCAND = (G < 64) && (E >= 8);   // per-group candidate lists
+    __shared__ float cand[(CAND || GCAND) ? kWavesPerBlock * kCandCap : 1];
     float z[E];
     load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
     WaveRed<G> red;
     int s, n = 0;
     float t, h = 0.0f;
-    sparsemax_row<E, 1, CAND>(z, red, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0), s, t);
+    if constexpr (GCAND)
+        sparsemax_row_group<E, G>(z, red, cand + (threadIdx.x >> 6) * kCandCap, s, t);
+    else
+        sparsemax_row<E, 1, CAND>(z, red, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0), s, t);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
