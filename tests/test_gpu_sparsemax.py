@@ -136,3 +136,40 @@ def test_large_sizes_properties(dev):
         dx = _native.sparsemax_bwd(dy, p, supp)
         assert torch.equal(dx != 0, (p != 0) & (dx != 0))
         assert torch.all(dx.double().sum(-1).abs() <= 1e-4)
+
+
+@pytest.mark.parametrize("R,K,sigma", [(1 << 20, 4096, 1.0), (1 << 20, 256, 1.0), (1 << 15, 65536, 1.0),
+                                       (1 << 18, 4096, 0.05)])
+def test_full_size_launches(dev, oracle_mod, R, K, sigma):
+    """BASELINE.json configs[2] at its real launch sizes (1M x 4096, 1M x 256, 32768 x 65536 per
+    launch; plus a wide-support case that takes the streaming backward).  Whole-tensor checks are
+    size-independent properties evaluated in row chunks; 1024 rows sampled across the launch are
+    compared with the CPU oracle (p, supp bit-exact; dx within 1e-6 of the row scale)."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(99)
+    x = torch.empty(R, K, device=dev).normal_(0.0, sigma, generator=g)
+    dy = torch.empty(R, K, device=dev).normal_(0.0, 1.0, generator=g)
+    p, supp, nnz, tau, _ = _native.sparsemax_fwd(x, want_nnz=True, want_tau=True)
+    dx = _native.sparsemax_bwd(dy, p, supp)
+    assert torch.equal(supp, nnz)
+    step = max(1, (1 << 26) // K)                      # 256 MB chunks
+    for lo in range(0, R, step):
+        sl = slice(lo, min(R, lo + step))
+        ps, dxs = p[sl], dx[sl]
+        assert bool((ps >= 0).all())
+        assert bool(((ps.sum(-1, dtype=torch.float64) - 1).abs() <= 3e-6).all())
+        assert torch.equal((ps > 0).sum(-1).to(torch.int32), supp[sl])
+        z = x[sl] - x[sl].max(dim=-1, keepdim=True)[0]
+        assert torch.equal(ps > 0, z > tau[sl].unsqueeze(-1))
+        assert bool(((dxs != 0) <= (ps != 0)).all())             # zero off the support
+        assert bool((dxs.sum(-1, dtype=torch.float64).abs() <= 1e-4).all())
+        del z
+    idx = torch.randint(0, R, (1024,), device=dev, generator=g)
+    idx[0], idx[-1] = 0, R - 1
+    xs, dys = x[idx].cpu().numpy(), dy[idx].cpu().numpy()
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(xs)
+    dx_ref = oracle_mod.sparsemax_bwd(dys, p_ref, s_ref)
+    assert np.array_equal(p[idx].cpu().numpy(), p_ref)
+    assert np.array_equal(supp[idx].cpu().numpy(), s_ref)
+    scale = np.abs(dys).max(axis=1, keepdims=True)
+    assert np.all(np.abs(dx[idx].cpu().numpy() - dx_ref) <= 1e-6 * scale)
