@@ -56,8 +56,20 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(8), i32(1), null) == -1           # k < 2
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(600), i32(4), null) == -2
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(40), i32(65), null) == -2
-    assert lib.smlvm_sparsemap_fwd(one, null, i32(0), i32(10), i64(2), i32(129), one, one, one, null, null, null, null) == -2
-    assert lib.smlvm_sparsemap_fwd(one, null, i32(-1), i32(10), i64(2), i32(16), one, one, one, null, null, null, null) == -1
+    assert lib.smlvm_sparsemap_fwd(one, null, i32(0), i32(10), i64(2), i32(129), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -2
+    assert lib.smlvm_sparsemap_fwd(one, null, i32(-1), i32(10), i64(2), i32(16), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -1
+    # n > 64 needs the tier workspace
+    assert lib.smlvm_sparsemap_fwd(one, null, i32(0), i32(10), i64(2), i32(100), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -4
+    lib.smlvm_sparsemap_fwd_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(64), i32(1)) == 0
+    assert lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(128), i32(0)) > lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(128), i32(1)) > 0
+    assert lib.smlvm_lowrank_ce_fwd(null, null, null, null, i32(0), null, null, null, i64(0), i32(784), i32(256), i32(5), null) == 0
+    assert lib.smlvm_lowrank_ce_fwd(null, null, null, null, i32(0), null, null, null, i64(2), i32(784), i32(256), i32(5), null) == -1
+    assert lib.smlvm_lowrank_ce_fwd(one, one, one, one, i32(0), one, one, null, i64(2), i32(784), i32(300), i32(5), null) == -2   # C > 256
+    assert lib.smlvm_lowrank_ce_fwd(one, one, one, one, i32(0), one, one, null, i64(2), i32(784), i32(256), i32(9), null) == -2   # R > 8
+    assert lib.smlvm_lowrank_ce_bwd(one, one, one, one, i32(0), one, one, null, one, one, i64(2), i32(784), i32(256), i32(5), null, ctypes.c_size_t(0), null) == -4
+    assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(0), null) == 0
+    assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(3), null) == -1
     assert lib.smlvm_support_compact(null, null, null, null, null, i64(3), i32(4), null) == -1
     lib.smlvm_support_offsets_workspace_bytes.restype = ctypes.c_size_t
     lib.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
