@@ -185,14 +185,23 @@ __device__ __forceinline__ void marginals(const uint32_t* cfg, const double* z, 
         moff[q] = 0.0;
     }
     const int sh = lane & 31;
+    if (m8 <= 0) return;
+    // operands of batch i0+8 are fetched while batch i0 is being added
+    double zz[8], zn[8];
+    uint32_t w[NK][8], wn[NK][8];
+    ld8(z, zz);
+#pragma unroll
+    for (int q = 0; q < NK; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[q][u] = cfg[u * WT + wi[q]];
+#pragma unroll 2
     for (int i0 = 0; i0 < m8; i0 += 8) {
-        double zz[8];
-        uint32_t w[NK][8];
-        ld8(z + i0, zz);
+        const int in = i0 + 8 < m8 ? i0 + 8 : m8 - 8;
+        ld8(z + in, zn);
 #pragma unroll
         for (int q = 0; q < NK; ++q)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w[q][u] = cfg[(i0 + u) * WT + wi[q]];
+            for (int u = 0; u < 8; ++u) wn[q][u] = cfg[(in + u) * WT + wi[q]];
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -203,6 +212,12 @@ __device__ __forceinline__ void marginals(const uint32_t* cfg, const double* z, 
                 mon[q] = __builtin_fma(zz[u], f_on, mon[q]);                   // == mon + z or mon + 0
                 moff[q] = __builtin_fma(zz[u], f_off, moff[q]);
             }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            zz[u] = zn[u];
+#pragma unroll
+            for (int q = 0; q < NK; ++q) w[q][u] = wn[q][u];
+        }
     }
 }
 
