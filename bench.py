@@ -360,6 +360,17 @@ def main():
             sweep[f"K{K}"] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "fwd_ms": fm,
                               "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
                               "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
+        # the other logit distributions of SURVEY.md 8(d) S1 at the headline shape: wide supports
+        # (every element within 1 of the row maximum: full-width threshold search, streaming backward)
+        for tag, sg in (("K4096_sigma0.05", 0.05), ("K4096_sigma0.2", 0.2)):
+            xs, dys = gen(1 << 20, 4096, sg, dev, 99)
+            w, fm, bm, ms_ = timed_sparsemax(native, xs, dys, max(3, a.steps // 4), 2, 1, dev)
+            del xs, dys
+            torch.cuda.empty_cache()
+            gb = 20.0 * 4096 * (1 << 20) / ((fm + bm) * 1e-3) / 1e9
+            sweep[tag] = {"rows_per_launch": 1 << 20, "launches_per_1M_rows": 1, "fwd_ms": fm, "bwd_ms": bm,
+                          "rows_per_s": (1 << 20) / ((fm + bm) * 1e-3), "GBps": gb,
+                          "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
         out["sweep"] = sweep
         out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, a.sigma),
