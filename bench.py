@@ -14,6 +14,7 @@ Extra objects on that line:
   roofline      dominant kernel: algorithmic bytes per launch / mean launch time (HIP events on the
                 launch stream inside the timed region) against the 8 TB/s HBM peak
   cpu_baseline  the CPU oracle (oracle/, plain C, 1 thread) timed on this host on a bounded sample
+  cpu_baseline_torch_all_cores  entmax's sort/cumsum algorithm in torch CPU ops on all host threads
   sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
   compaction    support count / compaction / weighted reduction kernels vs their algorithmic bytes
   sparsemap     batched active-set solver: samples/s and active-set iterations/s (N > 1: every rank
@@ -153,6 +154,26 @@ def cpu_baseline(K, sigma):
     return {"value": rows / t, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"{rows} rows x K={K} fp32 N(0,{sigma}^2), oracle/sparsemax_oracle.c fwd+bwd, "
                       f"{t:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def cpu_baseline_torch(K, sigma):
+    """entmax's algorithm in torch CPU ops (what the reference runs on a CPU), all host threads."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(1)
+    rows = max(64, (1 << 25) // K)          # 128 MB of logits
+    x = (sigma * rng.standard_normal((rows, K))).astype(np.float32)
+    dy = rng.standard_normal((rows, K)).astype(np.float32)
+    oracle.torch_sparsemax_fwd_bwd(x[:64], dy[:64])
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 5.0:
+        oracle.torch_sparsemax_fwd_bwd(x, dy)
+        reps += 1
+    t = time.perf_counter() - t0
+    return {"value": rows * reps / t, "unit": "rows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} x {rows} rows x K={K} fp32 N(0,{sigma}^2), entmax's sort/cumsum sparsemax fwd+bwd "
+                      f"in torch CPU ops, {t:.1f} s on {torch.get_num_threads()} threads of {os.cpu_count()} host cores"}
 
 
 def sparsemap_cpu_baseline(B, n, budget, sigma):
@@ -391,6 +412,7 @@ def main():
         out["train_steps"] = ts
     if rank == 0 and not _dist_on() and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
+        out["cpu_baseline_torch_all_cores"] = cpu_baseline_torch(a.K, a.sigma)
         out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(1024, 128, 0, 1.0)
     if rank == 0:
         print(json.dumps(out))

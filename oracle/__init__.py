@@ -212,3 +212,24 @@ def unpack_bits(aset_bits, n):
     a = np.asarray(aset_bits, np.uint32)
     k = np.arange(n)
     return ((a[..., k >> 5] >> (k & 31).astype(np.uint32)) & 1).astype(np.float32)
+
+
+def torch_sparsemax_fwd_bwd(x, dy):
+    """entmax's published sort/cumsum sparsemax and its backward written with torch CPU ops, i.e.
+    what the reference's `--mode marg --normalizer sparsemax` runs on a CPU (marg.py:45,51 ->
+    entmax.sparsemax).  Multi-threaded by torch; used as the all-cores CPU baseline of bench.py and
+    checked bit-exact against the C restatement in tests/test_oracle_sparsemax.py."""
+    import torch
+    X = torch.from_numpy(x)
+    X = X - X.max(dim=-1, keepdim=True)[0]
+    srt, _ = torch.sort(X, dim=-1, descending=True)
+    cs = srt.cumsum(dim=-1) - 1
+    rho = torch.arange(1, X.shape[-1] + 1, dtype=X.dtype)
+    supp = (rho * srt > cs).sum(dim=-1, keepdim=True)
+    tau = cs.gather(-1, supp - 1) / supp.to(X.dtype)
+    p = torch.clamp(X - tau, min=0)
+    g = torch.from_numpy(dy).clone()
+    g[p == 0] = 0
+    v = g.sum(dim=-1, keepdim=True) / supp.to(X.dtype)
+    dx = torch.where(p != 0, g - v, g)
+    return p.numpy(), supp.squeeze(-1).to(torch.int32).numpy(), dx.numpy()

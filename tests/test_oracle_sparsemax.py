@@ -142,3 +142,16 @@ def test_compaction_order_is_torch_nonzero_order():
     assert np.array_equal(rows, nz[:, 0]) and np.array_equal(cols, nz[:, 1])
     assert np.array_equal(vals, p[p > 0])
     assert np.array_equal(off, np.concatenate([[0], np.cumsum((p > 0).sum(-1))]))
+
+
+def test_torch_all_cores_baseline_matches_c_oracle(oracle_mod):
+    """bench.py's all-cores CPU baseline (oracle.torch_sparsemax_fwd_bwd) computes the same thing
+    as the C restatement: p, supp bit-exact; dx within 1e-6 of the row scale."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((257, 300)).astype(np.float32)
+    dy = rng.standard_normal((257, 300)).astype(np.float32)
+    p, s, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx = oracle_mod.sparsemax_bwd(dy, p, s)
+    p2, s2, dx2 = oracle_mod.torch_sparsemax_fwd_bwd(x, dy)
+    assert np.array_equal(p, p2) and np.array_equal(s, s2)
+    assert np.all(np.abs(dx - dx2) <= 1e-6 * np.abs(dy).max(axis=1, keepdims=True))
