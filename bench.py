@@ -92,20 +92,26 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
     p = torch.empty_like(x)
     dx = torch.empty_like(x)
     supp = torch.empty(R, dtype=torch.int32, device=dev)
+    cap = native.SUPPORT_COLS_CAP
+    cols = torch.empty((R, cap), dtype=torch.int32, device=dev)
     L = native.lib()
     import ctypes
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    # the pair lvmhelpers.functional.sparsemax runs: the forward also lists each row's support
+    # columns (128 B per row) and the backward works from the lists (include/sparsemarg.h)
     def fwd():
-        rc = L.smlvm_sparsemax_fwd(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(p.data_ptr()),
-                                   ctypes.c_void_p(supp.data_ptr()), None, None, None,
-                                   ctypes.c_int64(R), ctypes.c_int32(K), st)
+        rc = L.smlvm_sparsemax_fwd_cols(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(p.data_ptr()),
+                                        ctypes.c_void_p(supp.data_ptr()), None, None, None,
+                                        ctypes.c_void_p(cols.data_ptr()), ctypes.c_int32(cap),
+                                        ctypes.c_int64(R), ctypes.c_int32(K), st)
         assert rc == 0, rc
 
     def bwd():
-        rc = L.smlvm_sparsemax_bwd(ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(p.data_ptr()),
-                                   ctypes.c_void_p(supp.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
-                                   ctypes.c_int64(R), ctypes.c_int32(K), st)
+        rc = L.smlvm_sparsemax_bwd_cols(ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(cols.data_ptr()),
+                                        ctypes.c_int32(cap), ctypes.c_void_p(p.data_ptr()),
+                                        ctypes.c_void_p(supp.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
+                                        ctypes.c_int64(R), ctypes.c_int32(K), st)
         assert rc == 0, rc
 
     for _ in range(warmup):
@@ -339,6 +345,8 @@ def main():
             traffic = tj.get(f"{dom}_K{a.K}_R{a.rows}")
             for k in kern:
                 kern[k]["hbm_traffic_bytes"] = tj.get(f"{k}_K{a.K}_R{a.rows}")
+                if kern[k]["hbm_traffic_bytes"]:   # rate of the bytes that really crossed the HBM pins
+                    kern[k]["hbm_GBps"] = kern[k]["hbm_traffic_bytes"] / (kern[k]["ms"] * 1e-3) / 1e9
         except Exception:
             traffic = None
     out = {
@@ -364,9 +372,11 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "note": "achieved = algorithmic bytes (fwd 8K, bwd 12K per row) / measured time. The "
-                             "backward gathers dy only at the support of rows with <= 96 non-zeros, so its "
-                             "HBM traffic (PMC, `traffic`) is below its algorithmic bytes; see `kernels` "
-                             "for both launches and profiles/traffic.json for the counters."},
+                             "forward also writes each row's support list (<= 32 columns); the backward "
+                             "reads that list, gathers dy at those columns and writes dx without reading p "
+                             "or streaming dy, so its HBM traffic (PMC, profiles/traffic.json) is about a "
+                             "third of its algorithmic bytes; see `kernels` for both launches (`hbm_GBps` "
+                             "= PMC traffic / time)."},
         "kernels": kern,
     }
 

@@ -54,6 +54,21 @@ int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size, int32_t* n
 int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_size, float* dx,
                         int64_t R, int32_t K, void* stream);
 
+/* The same pair with a by-product that lets the backward skip p: the forward also writes the
+ * columns of the non-zeros of every row, the backward gathers dy at those columns and zero-fills dx
+ * (no read of p, no streaming read of dy: the backward of sparsemax is O(support) reads + one dense
+ * write).  What entmax keeps on the autograd ctx is (supp_size, p); this keeps (supp_size, lists).
+ *   support_cols [R, cap] int32, 1 <= cap <= 64: columns with p > 0 in no particular order, -1 in
+ *   unused slots; first entry -2 = no list for this row (more than cap non-zeros, or K > 4096): the
+ *   backward then reads p for that row exactly like smlvm_sparsemax_bwd.  support_cols may be NULL
+ *   (then these are the plain entry points). */
+int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
+                             float* entropy, int32_t* support_cols, int32_t cap, int64_t R,
+                             int32_t K, void* stream);
+int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32_t cap,
+                             const float* p, const int32_t* supp_size, float* dx, int64_t R,
+                             int32_t K, void* stream);
+
 /* Shannon entropy with exact zeros, lvmhelpers/marg.py:6-28 (also structmarg.py:9-20):
  * ent[r] = -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps), eps = FLT_EPSILON. */
 int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, void* stream);

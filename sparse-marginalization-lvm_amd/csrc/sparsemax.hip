@@ -298,11 +298,45 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// ------------------------------------------------------------------------------- support lists
+// Optional by-product of the forward: the columns of the non-zeros of every row, so that the
+// backward does not have to read p at all (p is zero almost everywhere; the backward then only
+// gathers dy at the listed columns and zero-fills dx).  Layout [R, cap] int32, cap <= 64: the
+// columns of p > 0 in no particular order, -1 in the unused slots; a first entry of -2 means "no
+// list for this row" (more than cap non-zeros, or a row wider than one wave's tile) and sends the
+// backward to the p-based path.
+constexpr int kColsNone = -1, kColsOverflow = -2, kColsMaxCap = 64;
+
+template <int E, bool VEC>
+__device__ __forceinline__ int col_of(int e, int gl, int GT)
+{
+    return VEC ? (((e >> 2) * GT + gl) * 4 + (e & 3)) : (e * GT + gl);
+}
+
+// bits of a wave-wide ballot that belong to this lane's group of G lanes: (count, count below me)
+template <int G>
+__device__ __forceinline__ void group_count(unsigned long long m, int gl, int grp, int& cnt, int& below)
+{
+    if constexpr (G == 64) {
+        cnt = __popcll(m);
+        below = lanes_below(m);
+    } else {
+        const unsigned group_bits = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+        const unsigned mine = (unsigned)(m >> (grp * G)) & group_bits;
+        cnt = __popc(mine);
+        below = __popc(mine & ((1u << gl) - 1u));
+    }
+}
+
+
 // Appends this wave's elements > thr to list[0..cap) in lane order per register; returns how many
 // there are (may exceed cap: then the list is incomplete and the caller must not use it).
-template <int E>
+// colbase/colstep: column of register e of this lane = colbase + (e >> 2) * colstep + (e & 3) for
+// the 16-byte layout, colbase + e * colstep for the scalar one (recorded next to the values when
+// `cols` is not null, for the support lists).
+template <int E, bool VEC>
 __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr, float* list,
-                                                  int cap)
+                                                  int cap, int* cols, int colbase, int colstep)
 {
     int base = 0;
 #pragma unroll
@@ -311,11 +345,42 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
         const unsigned long long m = __ballot(in);
         if (m != 0ull) {  // wave-uniform
             const int off = base + lanes_below(m);
-            if (in && off < cap) list[off] = z[e];
+            if (in && off < cap) {
+                list[off] = z[e];
+                if (cols) cols[off] = colbase + (VEC ? (e >> 2) * colstep + (e & 3) : e * colstep);
+            }
             base += __popcll(m);
         }
     }
     return base;
+}
+
+// Support list of a row from Q candidates per lane (value c[q], column cc[q]): the non-zeros of p
+// are the candidates above tau.  One lane group of G lanes per row.  The lane that fills slot 0
+// is also the one that overwrites it with the overflow mark (same thread, program order).
+template <int Q, int G>
+__device__ __forceinline__ void emit_cols_from_candidates(const float (&c)[Q], const int (&cc)[Q],
+                                                          float tau, int gl, int grp,
+                                                          int32_t* __restrict__ list, int cap, bool live)
+{
+    int base = 0;
+    bool wrote0 = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const bool nz = (c[q] - tau) > 0.0f;
+        const unsigned long long m = __ballot(nz);
+        if (m != 0ull) {
+            int cnt, below;
+            group_count<G>(m, gl, grp, cnt, below);
+            const int off = base + below;
+            if (nz && live && off < cap) { list[off] = cc[q]; wrote0 = wrote0 || off == 0; }
+            base += cnt;
+        }
+    }
+    if (live) {
+        if (base > cap) { if (wrote0) list[0] = kColsOverflow; }
+        else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
+    }
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -329,9 +394,12 @@ __device__ __forceinline__ void wave_lds_sync()
 // z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
 // NW = waves holding the row (1: a lane group of one wave; then G < 64 skips the candidate path).
 // cand: LDS, NW == 1: kCandCap floats private to this wave; NW > 1: NW*64 floats + NW ints.
-template <int E, int NW, bool CAND, class Red>
-__device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
-                                              float& tau_out)
+// list != null (NW == 1 only): the row's support list is wanted; returns true if it was written
+// here (from the candidates), false if the caller has to scan the registers.
+template <int E, int NW, bool CAND, bool VEC, class Red>
+__device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
+                                              float& tau_out, int32_t* list = nullptr, int cap = 0,
+                                              bool live = true)
 {
     float mx = z[0];
 #pragma unroll
@@ -346,20 +414,26 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* ca
     if constexpr (CAND) {
         const int lane = threadIdx.x & 63;
         float c[kCandPerLane];
+        int cc[kCandPerLane];
         if constexpr (NW == 1) {
-            const int n_c = compact_candidates(z, -1.0f, cand, kCandCap);
+            int* ccols = list ? reinterpret_cast<int*>(cand + kCandCap) : nullptr;
+            const int n_c = compact_candidates<E, VEC>(z, -1.0f, cand, kCandCap, ccols,
+                                                       VEC ? lane * 4 : lane, VEC ? 256 : 64);
             fast = n_c <= kCandCap;
             if (fast) {
                 wave_lds_sync();
 #pragma unroll
-                for (int q = 0; q < kCandPerLane; ++q)
-                    c[q] = (lane + 64 * q < n_c) ? cand[lane + 64 * q] : -INFINITY;
+                for (int q = 0; q < kCandPerLane; ++q) {
+                    const bool have = lane + 64 * q < n_c;
+                    c[q] = have ? cand[lane + 64 * q] : -INFINITY;
+                    cc[q] = (have && list) ? ccols[lane + 64 * q] : 0;
+                }
                 wave_lds_sync();
             }
         } else {
             const int wave = threadIdx.x >> 6;
             int* cnt = reinterpret_cast<int*>(cand + NW * 64);
-            const int n_w = compact_candidates(z, -1.0f, cand + wave * 64, 64);
+            const int n_w = compact_candidates<E, VEC>(z, -1.0f, cand + wave * 64, 64, nullptr, 0, 0);
             if (lane == 0) cnt[wave] = n_w;
             __syncthreads();
             int total = 0, worst = 0;
@@ -390,6 +464,12 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* ca
         if (fast) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers
             solve_core(c, wred, s_final, S_final);
+            if constexpr (NW == 1) {
+                if (list) {
+                    const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+                    emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap, live);
+                }
+            }
         }
     }
     if (!fast) solve_core(z, red, s_final, S_final);
@@ -400,6 +480,7 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* ca
     for (int e = 0; e < E; ++e) z[e] = fmaxf(z[e] - tau_f, 0.0f);
     supp = s_final;
     tau_out = tau_f;
+    return fast && list != nullptr;
 }
 
 // Same idea for rows held by a lane group of G < 64 lanes (K <= 512, several rows per wave): each
@@ -407,9 +488,11 @@ __device__ __forceinline__ void sparsemax_row(float (&z)[E], Red& red, float* ca
 // a lane looks at its group's bits only) and the threshold search runs on Q values per lane
 // instead of E.  If any row of the wave has more candidates than its slice holds, the whole wave
 // takes the full-width search.
-template <int E, int G>
-__device__ __forceinline__ void sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand,
-                                                    int& supp, float& tau_out)
+template <int E, int G, bool VEC>
+__device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand,
+                                                    int& supp, float& tau_out,
+                                                    int32_t* list = nullptr, int cap = 0,
+                                                    bool live = true)
 {
     static_assert(G < 64, "lane groups inside one wave");
     constexpr int Q = (G >= 16) ? 2 : 32 / G;   // candidates per lane: capacity G*Q = 32, 32, 64
@@ -424,7 +507,8 @@ __device__ __forceinline__ void sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G;
     const unsigned group_bits = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
     const unsigned below_bits = (1u << gl) - 1u;
-    float* list = cand + grp * CAP;
+    float* clist = cand + grp * CAP;
+    int* ccols = reinterpret_cast<int*>(cand + kCandCap) + grp * CAP;
     int base = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -433,19 +517,33 @@ __device__ __forceinline__ void sparsemax_row_group(float (&z)[E], WaveRed<G>& r
         if (m != 0ull) {  // wave-uniform
             const unsigned mine = (unsigned)(m >> (grp * G)) & group_bits;
             const int off = base + __popc(mine & below_bits);
-            if (in && off < CAP) list[off] = z[e];
+            if (in && off < CAP) {
+                clist[off] = z[e];
+                if (list) ccols[off] = col_of<E, VEC>(e, gl, G);
+            }
             base += __popc(mine);
         }
     }
     int s_final = 1;
     double S_final = 0.0;
+    bool listed = false;
     if (__ballot(base > CAP) == 0ull) {
         float c[Q];
+        int cc[Q];
         wave_lds_sync();
 #pragma unroll
-        for (int q = 0; q < Q; ++q) c[q] = (gl + G * q < base) ? list[gl + G * q] : -INFINITY;
+        for (int q = 0; q < Q; ++q) {
+            const bool have = gl + G * q < base;
+            c[q] = have ? clist[gl + G * q] : -INFINITY;
+            cc[q] = (have && list) ? ccols[gl + G * q] : 0;
+        }
         wave_lds_sync();
         solve_core(c, red, s_final, S_final);
+        if (list) {
+            const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+            emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live);
+            listed = true;
+        }
     } else {
         solve_core(z, red, s_final, S_final);
     }
@@ -455,6 +553,7 @@ __device__ __forceinline__ void sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     for (int e = 0; e < E; ++e) z[e] = fmaxf(z[e] - tau_f, 0.0f);
     supp = s_final;
     tau_out = tau_f;
+    return listed;
 }
 
 template <int E, class Red>
@@ -585,6 +684,116 @@ __device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, 
     }
 }
 
+// Register scan (rows that took the full-width threshold search): one pass; the lane that fills
+// slot 0 overwrites it with the overflow mark if the row has more than cap non-zeros.
+template <int E, int G, bool VEC>
+__device__ __forceinline__ void emit_support_cols(const float (&p)[E], int gl, int grp,
+                                                  int32_t* __restrict__ list, int cap, bool live)
+{
+    int base = 0;
+    bool wrote0 = false;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool nz = p[e] > 0.0f;
+        const unsigned long long m = __ballot(nz);
+        if (m != 0ull) {
+            int cnt, below;
+            group_count<G>(m, gl, grp, cnt, below);
+            const int off = base + below;
+            if (nz && live && off < cap) { list[off] = col_of<E, VEC>(e, gl, G); wrote0 = wrote0 || off == 0; }
+            base += cnt;
+        }
+    }
+    if (live) {
+        if (base > cap) { if (wrote0) list[0] = kColsOverflow; }
+        else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
+    }
+}
+
+// dx of a row from its support list, in two rounds of stores: the whole row as zeros (no
+// dependence on anything, issued before the list has even arrived), then -- once those stores
+// have been acknowledged by the L2 (vmcnt == 0) -- the few values dy[col] - mean at the listed
+// columns.  Both rounds come from the same wave, so they reach the same L2 in that order.  No
+// register tile, no read of p, no streaming read of dy.  Slot j of the list is held by lane j % G
+// of the row's lane group.
+template <int E, int G, bool VEC, bool FULL>
+__device__ __forceinline__ void bwd_row_from_cols(const float* __restrict__ dyrow,
+                                                  float* __restrict__ dxrow,
+                                                  const int32_t* __restrict__ list, int cap, int K,
+                                                  int gl, int s, bool live, WaveRed<G>& red)
+{
+    constexpr int MAXS = kColsMaxCap / G;   // slots per lane
+    int c[MAXS];
+    float v[MAXS];
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        const int j = gl + G * q;
+        c[q] = (j < cap) ? list[j] : kColsNone;
+    }
+    if (live) {
+        float zero[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zero[e] = 0.0f;
+        store_row<E, VEC, FULL>(dxrow, K, gl, G, zero);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        v[q] = 0.0f;
+        if (c[q] >= 0) v[q] = dyrow[c[q]];
+        acc += (double)v[q];
+    }
+    acc = red.sum(acc);
+    const float mean = (float)acc / (float)s;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q)
+        if (live && c[q] >= 0) dxrow[c[q]] = v[q] - mean;
+}
+
+// Small tiles (E <= 16): the row's dx is built in registers instead -- every entry of the list is
+// broadcast through the lane group and placed with E compare-selects -- and stored once; partial
+// writes into 1 KB rows cost more than they save.
+template <int E, int G, bool VEC>
+__device__ __forceinline__ void bwd_tile_from_cols(const float* __restrict__ dyrow,
+                                                   const int32_t* __restrict__ list, int cap, int gl,
+                                                   int lane, int s, WaveRed<G>& red, float (&a)[E])
+{
+    constexpr int MAXS = kColsMaxCap / G;
+    int c[MAXS];
+    float v[MAXS];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        const int j = gl + G * q;
+        c[q] = (j < cap) ? list[j] : kColsNone;
+        v[q] = 0.0f;
+        if (c[q] >= 0) v[q] = dyrow[c[q]];
+        acc += (double)v[q];
+    }
+    acc = red.sum(acc);
+    const float mean = (float)acc / (float)s;
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] = 0.0f;
+    const int gbase = lane - gl;
+    const int col0 = col_of<E, VEC>(0, gl, G);
+#pragma unroll
+    for (int q = 0; q < MAXS; ++q) {
+        for (int jj = 0; jj < G; ++jj) {
+            const int col = __shfl(c[q], gbase + jj);
+            if (__ballot(col >= 0) == 0ull) break;          // lists are packed: nothing further
+            const float val = __shfl(v[q], gbase + jj) - mean;
+            const int rel = col - col0;                      // negative for the sentinels
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int want = VEC ? ((e >> 2) * G * 4 + (e & 3)) : e * G;
+                a[e] = (col >= 0 && rel == want) ? val : a[e];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- kernels
 constexpr int kWavesPerBlock = 4;
 
@@ -601,12 +810,14 @@ __device__ __forceinline__ unsigned xcd_block()
 // waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
 constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
 constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
+constexpr int bwd_cols_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 
 // EXTRA: any of the optional outputs (nnz, tau, entropy) requested.
 template <int G, int E, bool VEC, bool FULL, bool EXTRA>
 __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void sparsemax_fwd_wave_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
-    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent, int64_t R, int K)
+    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
+    int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
@@ -616,17 +827,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
     constexpr bool GCAND = (G < 64) && (E >= 8);   // per-group candidate lists
-    __shared__ float cand[(CAND || GCAND) ? kWavesPerBlock * kCandCap : 1];
+    // per wave: kCandCap candidate values followed by kCandCap candidate columns
+    __shared__ float cand[(CAND || GCAND) ? kWavesPerBlock * 2 * kCandCap : 1];
     float z[E];
     load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
     WaveRed<G> red;
     int s, n = 0;
     float t, h = 0.0f;
+    int32_t* list = cols ? cols + row * cap : nullptr;
+    bool listed;
     if constexpr (GCAND)
-        sparsemax_row_group<E, G>(z, red, cand + (threadIdx.x >> 6) * kCandCap, s, t);
+        listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, s, t,
+                                                list, cap, live);
     else
-        sparsemax_row<E, 1, CAND>(z, red, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0), s, t);
+        listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
+                                                s, t, list, cap, live);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
+    if (cols && !listed) emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live);
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
         if (gl == 0) {
@@ -643,7 +860,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
 template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
 __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
-    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent, int64_t R, int K)
+    int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
+    int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
     __shared__ float cand[NW * 64 + NW];
@@ -653,11 +871,12 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
         BlockRed<NW> red(lds);
         int s, n = 0;
         float t, h = 0.0f;
-        sparsemax_row<E, NW, true>(z, red, cand, s, t);
+        sparsemax_row<E, NW, true, VEC>(z, red, cand, s, t);
         if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
         store_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, z);
         if (threadIdx.x == 0) {
             supp[row] = s;
+            if (cols) cols[row * cap] = kColsOverflow;   // rows wider than a wave tile: no list
             if constexpr (EXTRA) {
                 if (nnz) nnz[row] = n;
                 if (tau) tau[row] = t;
@@ -694,6 +913,44 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     const int s = supp[row];
     WaveRed<G> red;
     if (__ballot(s > kGatherMaxSupport) == 0ull) {   // every row of this wave has a small support
+        float a[E];
+        load_row<E, VEC, FULL>(p + row * K, K, gl, G, a, 0.0f);
+        bwd_row_gather<E, VEC>(dy + row * K, gl, G, a, s, red);
+        if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+    } else {
+        float g[E], pv[E];
+        load_row<E, VEC, FULL>(p + row * K, K, gl, G, pv, 0.0f);
+        load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+        bwd_row(g, pv, s, red);
+        if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
+    }
+}
+
+// Backward from the forward's support lists: no read of p, no streaming read of dy; writes dx.
+template <int G, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void sparsemax_bwd_cols_wave_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ cols, int cap,
+    const float* __restrict__ p, const int32_t* __restrict__ supp, float* __restrict__ dx, int64_t R,
+    int K)
+{
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int gl = lane % G;
+    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool live = row < R;
+    if (!live) row = R - 1;
+    const int s = supp[row];
+    const int32_t* list = cols + row * cap;
+    WaveRed<G> red;
+    if (__ballot(list[0] == kColsOverflow) == 0ull) {   // every row of this wave has its list
+        if constexpr (E <= 16) {
+            float a[E];
+            bwd_tile_from_cols<E, G, VEC>(dy + row * K, list, cap, gl, lane, s, red, a);
+            if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+        } else {
+            bwd_row_from_cols<E, G, VEC, FULL>(dy + row * K, dx + row * K, list, cap, K, gl, s, live, red);
+        }
+    } else if (__ballot(s > kGatherMaxSupport) == 0ull) {
         float a[E];
         load_row<E, VEC, FULL>(p + row * K, K, gl, G, a, 0.0f);
         bwd_row_gather<E, VEC>(dy + row * K, gl, G, a, s, red);
@@ -758,11 +1015,13 @@ struct FwdArgs {
     const float* x; float* p; int32_t* supp; int32_t* nnz; float* tau; float* ent;
     int64_t R; int K; hipStream_t st;
     bool vec, extra;
+    int32_t* cols; int cap;
 };
 struct BwdArgs {
     const float* dy; const float* p; const int32_t* supp; float* dx;
     int64_t R; int K; hipStream_t st;
     bool vec;
+    const int32_t* cols; int cap;
 };
 
 static unsigned wave_grid(int64_t R, int G)
@@ -777,19 +1036,25 @@ static void fwd_wave_go(const FwdArgs& a)
 {
     hipLaunchKernelGGL((sparsemax_fwd_wave_kernel<G, E, VEC, FULL, EXTRA>), dim3(wave_grid(a.R, G)),
                        dim3(64 * kWavesPerBlock), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent,
-                       a.R, a.K);
+                       a.cols, a.cap, a.R, a.K);
 }
 template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
 static void fwd_block_go(const FwdArgs& a)
 {
     hipLaunchKernelGGL((sparsemax_fwd_block_kernel<NW, E, VEC, FULL, EXTRA>), dim3(block_grid(a.R)),
-                       dim3(64 * NW), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent, a.R, a.K);
+                       dim3(64 * NW), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent, a.cols, a.cap,
+                       a.R, a.K);
 }
 template <int G, int E, bool VEC, bool FULL>
 static void bwd_wave_go(const BwdArgs& a)
 {
-    hipLaunchKernelGGL((sparsemax_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
-                       dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
+    if (a.cols)
+        hipLaunchKernelGGL((sparsemax_bwd_cols_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
+                           dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.cols, a.cap, a.p, a.supp, a.dx,
+                           a.R, a.K);
+    else
+        hipLaunchKernelGGL((sparsemax_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
+                           dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
 }
 template <int NW, int E, bool VEC, bool FULL>
 static void bwd_block_go(const BwdArgs& a)
@@ -861,7 +1126,22 @@ extern "C" int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size,
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
-              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy};
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, nullptr, 0};
+    SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz,
+                                        float* tau, float* entropy, int32_t* support_cols,
+                                        int32_t cap, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap};
     SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
@@ -874,7 +1154,23 @@ extern "C" int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
-              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx)};
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx), nullptr, 0};
+    SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32_t cap,
+                                        const float* p, const int32_t* supp_size, float* dx,
+                                        int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
+              K <= 4096 ? support_cols : nullptr, cap};   // wider rows have no lists (block kernels)
     SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }

@@ -16,7 +16,8 @@ _lib = None
 
 ABI_SYMBOLS = [
     "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error",
-    "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_entropy",
+    "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
+    "smlvm_sparsemax_bwd_cols", "smlvm_entropy",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
     "smlvm_support_compact", "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
@@ -87,8 +88,12 @@ _f32 = ctypes.c_float
 
 
 # ----------------------------------------------------------------------------------- sparsemax
-def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False):
-    """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None)."""
+SUPPORT_COLS_CAP = 32   # slots per row of the forward's support list (128 B per row)
+
+
+def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False):
+    """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None).
+    want_cols=True appends the support lists [R, SUPPORT_COLS_CAP] i32 for sparsemax_bwd_cols."""
     x = _need_gpu(x, torch.float32, "x")
     R, K = x.shape
     p = torch.empty_like(x)
@@ -96,10 +101,31 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False):
     nnz = torch.empty(R, dtype=torch.int32, device=x.device) if want_nnz else None
     tau = torch.empty(R, dtype=torch.float32, device=x.device) if want_tau else None
     ent = torch.empty(R, dtype=torch.float32, device=x.device) if want_entropy else None
+    if not want_cols:
+        with torch.cuda.device(x.device):
+            _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
+                                             _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
+        return p, supp, nnz, tau, ent
+    cols = torch.empty((R, SUPPORT_COLS_CAP), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
-                                         _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
-    return p, supp, nnz, tau, ent
+        _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
+                                              _p(cols), _i32(SUPPORT_COLS_CAP), _i64(R), _i32(K),
+                                              _stream()), "smlvm_sparsemax_fwd_cols")
+    return p, supp, nnz, tau, ent, cols
+
+
+def sparsemax_bwd_cols(dy, cols, p, supp):
+    """Backward from the forward's support lists (p is only read for rows without a list)."""
+    dy = _need_gpu(dy, torch.float32, "dy")
+    p = _need_gpu(p, torch.float32, "p")
+    cols = _need_gpu(cols, torch.int32, "cols")
+    R, K = p.shape
+    dx = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_sparsemax_bwd_cols(_p(dy), _p(cols), _i32(cols.shape[1]), _p(p), _p(supp),
+                                              _p(dx), _i64(R), _i32(K), _stream()),
+               "smlvm_sparsemax_bwd_cols")
+    return dx
 
 
 def sparsemax_bwd(dy, p, supp):

@@ -10,14 +10,14 @@ class _Sparsemax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         shape = x.shape
-        p, supp, _, _, _ = _native.sparsemax_fwd(x.reshape(-1, shape[-1]))
-        ctx.save_for_backward(p, supp)
+        p, supp, _, _, _, cols = _native.sparsemax_fwd(x.reshape(-1, shape[-1]), want_cols=True)
+        ctx.save_for_backward(p, supp, cols)
         return p.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        p, supp = ctx.saved_tensors
-        dx = _native.sparsemax_bwd(dy.reshape(p.shape), p, supp)
+        p, supp, cols = ctx.saved_tensors
+        dx = _native.sparsemax_bwd_cols(dy.reshape(p.shape).contiguous(), cols, p, supp)
         return dx.view(dy.shape)
 
 
@@ -26,14 +26,14 @@ class _SparsemaxEntropy(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        p, supp, _, _, ent = _native.sparsemax_fwd(x, want_entropy=True)
-        ctx.save_for_backward(p, supp)
+        p, supp, _, _, ent, cols = _native.sparsemax_fwd(x, want_entropy=True, want_cols=True)
+        ctx.save_for_backward(p, supp, cols)
         ctx.mark_non_differentiable(supp)
         return p, ent, supp
 
     @staticmethod
     def backward(ctx, dp, dent, _dsupp):
-        p, supp = ctx.saved_tensors
+        p, supp, cols = ctx.saved_tensors
         if dp is None and dent is None:
             return torch.zeros_like(p)
         if dent is None:
@@ -42,7 +42,7 @@ class _SparsemaxEntropy(torch.autograd.Function):
             g = _entropy_vjp(p, dent)
         else:
             g = dp + _entropy_vjp(p, dent)
-        return _native.sparsemax_bwd(g.contiguous(), p, supp)
+        return _native.sparsemax_bwd_cols(g.contiguous(), cols, p, supp)
 
 
 def _entropy_vjp(p, dent):

@@ -149,8 +149,11 @@ def test_full_size_launches(dev, oracle_mod, R, K, sigma):
     g = torch.Generator(device=dev).manual_seed(99)
     x = torch.empty(R, K, device=dev).normal_(0.0, sigma, generator=g)
     dy = torch.empty(R, K, device=dev).normal_(0.0, 1.0, generator=g)
-    p, supp, nnz, tau, _ = _native.sparsemax_fwd(x, want_nnz=True, want_tau=True)
-    dx = _native.sparsemax_bwd(dy, p, supp)
+    p, supp, nnz, tau, _, cols = _native.sparsemax_fwd(x, want_nnz=True, want_tau=True, want_cols=True)
+    dx_p = _native.sparsemax_bwd(dy, p, supp)           # reads p
+    dx = _native.sparsemax_bwd_cols(dy, cols, p, supp)  # reads the support lists
+    assert bool(((dx - dx_p).abs() <= 1e-6 * dy.abs().amax(dim=-1, keepdim=True)).all())
+    del dx_p
     assert torch.equal(supp, nnz)
     step = max(1, (1 << 26) // K)                      # 256 MB chunks
     for lo in range(0, R, step):
@@ -173,3 +176,32 @@ def test_full_size_launches(dev, oracle_mod, R, K, sigma):
     assert np.array_equal(supp[idx].cpu().numpy(), s_ref)
     scale = np.abs(dys).max(axis=1, keepdims=True)
     assert np.all(np.abs(dx[idx].cpu().numpy() - dx_ref) <= 1e-6 * scale)
+
+
+@pytest.mark.parametrize("kind", ["normal", "narrow", "adversarial"])
+@pytest.mark.parametrize("R,K", SHAPES)
+def test_support_lists_and_list_backward(dev, oracle_mod, R, K, kind):
+    """Forward by-product: the columns of p > 0 per row (any order, -1 padding, -2 = no list), and
+    the backward that uses them instead of reading p.  The lists must name exactly the oracle's
+    non-zeros; dx must match the oracle like the p-based backward does."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(7 * R + K)
+    x = _rows(rng, R, K, kind)
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    p, supp, _, _, _, cols = _native.sparsemax_fwd(torch.from_numpy(x).to(dev), want_cols=True)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    c = cols.cpu().numpy()
+    cap = c.shape[1]
+    for r in range(R):
+        nz = np.flatnonzero(p_ref[r] > 0)
+        if K > 4096 or nz.size > cap:
+            assert c[r, 0] == -2
+        else:
+            assert sorted(c[r, :nz.size].tolist()) == nz.tolist()
+            assert np.all(c[r, nz.size:] == -1)
+    dx = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp).cpu().numpy()
+    scale = np.maximum(np.abs(dy).max(axis=1, keepdims=True), 1e-30)
+    assert np.all(np.abs(dx - dx_ref) <= 1e-6 * scale)
+    assert np.array_equal(dx != 0, (p_ref != 0) & (dx != 0))

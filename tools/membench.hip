@@ -134,6 +134,21 @@ __global__ __launch_bounds__(BS) void k_copy_tile_xcd(const float4* __restrict__
     for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], d4 + u * 64 + lane); else d4[u * 64 + lane] = v[u]; }
 }
 
+// write-only tile: each wave zero-fills U KB (the sparse backward's shape)
+template <int U, bool NT, int BS, bool REMAP>
+__global__ __launch_bounds__(BS) void k_fill_tile(float4* __restrict__ o, size_t n)
+{
+    const unsigned nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
+    const unsigned lb = (REMAP && b < (per << 3)) ? (b & 7u) * per + (b >> 3) : b;
+    size_t wave = ((size_t)lb * BS + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4* d4 = reinterpret_cast<f4*>(o + wave * (64 * U));
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(z, d4 + u * 64 + lane); else d4[u * 64 + lane] = z; }
+}
+
 template <class F>
 static double timeit(F f, int reps = 10)
 {
@@ -157,6 +172,13 @@ int main(int argc, char** argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
     double t;
+    if (argc > 3) {
+#define FL(U, NT, BS, RM) t = timeit([&] { k_fill_tile<U, NT, BS, RM><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(o, n); }); \
+    printf("fill tile U=%d nt=%d BS=%d remap=%d: %.2f TB/s\n", U, (int)NT, BS, (int)RM, 1.0 * bytes / t / 1e12);
+        FL(16, true, 256, true) FL(16, true, 256, false) FL(16, false, 256, true) FL(16, false, 256, false)
+        FL(4, true, 256, false) FL(1, true, 256, false) FL(1, false, 256, false) FL(16, true, 64, false) FL(16, true, 1024, true)
+        return 0;
+    }
     if (argc > 2) {
 #define XC(U, NT, BS, CH) t = timeit([&] { k_copy_tile_xcd<U, NT, BS, CH><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(a, o, n); }); \
     printf("copy tile xcd-remap U=%d nt=%d BS=%d chunk=%d: %.2f TB/s\n", U, (int)NT, BS, CH, 2.0 * bytes / t / 1e12);

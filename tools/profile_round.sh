@@ -20,6 +20,9 @@ if [ "${2:-}" != "skip-tests" ]; then
 fi
 timeout -k 10 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err" || { echo bench failed; tail "$OUT/bench.err"; exit 1; }
 step 300 "$OUT/rocprof_stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu
+# the headline workload alone: the sweep launches the same kernel templates on other inputs, which
+# would mix into the per-kernel averages above
+step 200 "$OUT/rocprof_stats_main.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_main" -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-sweep
 step 120 "$OUT/pmc_fetch.log" timeout -s KILL 110 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-sweep
 step 120 "$OUT/pmc_write.log" timeout -s KILL 110 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-sweep
 # keep only the small summaries (traces of 1M-row launches are small anyway; PMC csv can be big)
