@@ -343,7 +343,7 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
     for (int e = 0; e < E; ++e) {
         const bool in = z[e] > thr;
         const unsigned long long m = __ballot(in);
-        if (m != 0ull) {  // wave-uniform
+        if (m != 0ull && base <= cap) {  // wave-uniform; past cap the list is already useless
             const int off = base + lanes_below(m);
             if (in && off < cap) {
                 list[off] = z[e];
@@ -354,6 +354,16 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
     }
     return base;
 }
+
+// Rows with more than kCandCap elements within 1 of the maximum (narrow logit distributions): a
+// few full-width Michelot steps raise the bound tau_k <= tau first, and the candidates are taken
+// above tau_k - kLazyMargin instead.  The fp32 sums behind tau_k are off by far less than the
+// margin (<= 70 roundings of 2^-24 each on values in [-1, 0]), and the oracle's own fp32 test
+// cannot admit an element more than ~1e-6 below tau, so the list still holds the whole support
+// and the elements its edge test can look at.
+constexpr int kLazyPasses = 8;
+constexpr int kLazyTry = 2 * kCandCap;      // attempt the compaction once |{z > tau_k}| is below this
+constexpr float kLazyMargin = 1e-3f;
 
 // Support list of a row from Q candidates per lane (value c[q], column cc[q]): the non-zeros of p
 // are the candidates above tau.  One lane group of G lanes per row.  The lane that fills slot 0
@@ -417,8 +427,32 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
         int cc[kCandPerLane];
         if constexpr (NW == 1) {
             int* ccols = list ? reinterpret_cast<int*>(cand + kCandCap) : nullptr;
-            const int n_c = compact_candidates<E, VEC>(z, -1.0f, cand, kCandCap, ccols,
-                                                       VEC ? lane * 4 : lane, VEC ? 256 : 64);
+            const int colbase = VEC ? lane * 4 : lane, colstep = VEC ? 256 : 64;
+            int n_c = compact_candidates<E, VEC>(z, -1.0f, cand, kCandCap, ccols, colbase, colstep);
+            if (n_c > kCandCap) {
+                float tau = -1.0f;
+                int cnt_prev = 0x7fffffff;
+                for (int pass = 0; pass < kLazyPasses; ++pass) {
+                    int cn = 0;
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool in = z[e] > tau;
+                        cn += in ? 1 : 0;
+                        sm += in ? z[e] : 0.0f;
+                    }
+                    red.cs(cn, sm);
+                    if (cn >= cnt_prev) break;   // fixed point with a wide support: full-width search
+                    cnt_prev = cn;
+                    tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+                    if (cn <= kLazyTry) {
+                        wave_lds_sync();
+                        n_c = compact_candidates<E, VEC>(z, tau - kLazyMargin, cand, kCandCap, ccols,
+                                                         colbase, colstep);
+                        if (n_c <= kCandCap) break;
+                    }
+                }
+            }
             fast = n_c <= kCandCap;
             if (fast) {
                 wave_lds_sync();
@@ -608,7 +642,8 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, i
         for (int i = 0; i < E / 4; ++i) {
             int f = i * GT + gl;
             float4 v = make_float4(pad, pad, pad, pad);
-            if (FULL || f < K4) v = nt_load4(r4 + f);
+            // (uniform base of each group of 4 chunks) + (lane offset) + (immediate < 4 KB)
+            if (FULL || f < K4) v = nt_load4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl));
             z[4 * i + 0] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
         }
     } else {
@@ -630,7 +665,9 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
 #pragma unroll
         for (int i = 0; i < E / 4; ++i) {
             int f = i * GT + gl;
-            if (FULL || f < K4) nt_store4(r4 + f, make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]));
+            if (FULL || f < K4)
+                nt_store4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl),
+                          make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]));
         }
     } else {
 #pragma unroll
@@ -807,6 +844,20 @@ __device__ __forceinline__ unsigned xcd_block()
     const unsigned nb = gridDim.x, b = blockIdx.x, per = nb >> 3;
     return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
 }
+// First row of this lane's group.  One row per wave (G == 64): the wave index goes through
+// readfirstlane so that the row, its base addresses and `live` are scalar -- loads and stores then
+// use the SGPR-base + 32-bit-lane-offset form instead of sixteen 64-bit VGPR addresses per tensor
+// (which the register allocator used to spill).
+template <int G>
+__device__ __forceinline__ int64_t wave_row(int lane)
+{
+    if constexpr (G == 64) {
+        const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        return (int64_t)xcd_block<true>() * kWavesPerBlock + wave;
+    } else {
+        return ((int64_t)xcd_block<false>() * kWavesPerBlock + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+    }
+}
 // waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
 constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
 constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
@@ -822,7 +873,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
-    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    int64_t row = wave_row<G>(lane);
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
@@ -907,7 +958,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
-    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    int64_t row = wave_row<G>(lane);
     const bool live = row < R;
     if (!live) row = R - 1;
     const int s = supp[row];
@@ -936,7 +987,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
-    int64_t row = ((int64_t)xcd_block<(G == 64)>() * kWavesPerBlock + (threadIdx.x >> 6)) * RPW + lane / G;
+    int64_t row = wave_row<G>(lane);
     const bool live = row < R;
     if (!live) row = R - 1;
     const int s = supp[row];
