@@ -171,6 +171,27 @@ __device__ __forceinline__ bool cond_rank(int m_gt, double S_gt, float v, int r)
     return j * v > c;
 }
 
+// rank 1 of the tie group below (m, S) fails the test, but by no more than rounding noise
+__device__ __forceinline__ bool near_rank(int m, double S_m, float v)
+{
+    const float jv = (float)(m + 1) * v;
+    const float Sf = (float)(S_m + (double)v);
+    const float c = Sf - 1.0f;
+    const float scale = fmaxf(fmaxf(fabsf(jv), fabsf(Sf)), 1.0f);
+    return c - jv <= 1e-6f * scale;
+}
+
+constexpr int kTieExact = 64;
+
+// Number of ranks r = 1..t of a tie group whose test holds.  Rare (ties exactly at the edge), so it
+// is kept out of line: inlined three times it cost the small-row kernels their register budget.
+__device__ __noinline__ int count_ranks(int m_gt, double S_gt, float v, int t)
+{
+    int n = 0;
+    for (int r = 1; r <= t; ++r) n += cond_rank(m_gt, S_gt, v, r) ? 1 : 0;
+    return n;
+}   // tie groups at the edge up to this size are counted rank by rank
+
 struct Edge {
     int m_gt, t;
     double S_gt;
@@ -240,10 +261,22 @@ __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int& s
     int s_final;
     double S_final;
     int dir = 0;
+    bool probe = false;
     for (;;) {
         Edge b = edge_pass(z, lo, red);
+        if (probe) {   // b = the tie group just below a support that is otherwise settled
+            int cnt = 0;
+            if (b.t > 1 && b.t <= kTieExact) cnt = count_ranks(b.m_gt, b.S_gt, lo, b.t);
+            s_final = b.m_gt + cnt;
+            S_final = b.S_gt + (double)cnt * (double)lo;
+            break;
+        }
         int rstar;
-        if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
+        if (b.t > 1 && b.t <= kTieExact) {
+            // the oracle's support size is the NUMBER of ranks whose test holds; inside a small tie
+            // group at the edge rounding can make that pattern non-monotone (fail, pass), so count
+            rstar = count_ranks(b.m_gt, b.S_gt, lo, b.t);
+        } else if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
             rstar = b.t;
         } else if (b.t == 1 || !cond_rank(b.m_gt, b.S_gt, lo, 1)) {
             rstar = 0;
@@ -258,10 +291,20 @@ __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int& s
         if (rstar == b.t) {
             int m = b.m_gt + b.t;
             double S_m = b.S_gt + (double)b.t * (double)lo;
-            if (dir >= 0 && b.vnext > -INFINITY && cond_rank(m, S_m, b.vnext, 1)) {
-                dir = 1;  // the next group still passes the test: grow
-                lo = b.vnext;
-                continue;
+            if (dir >= 0 && b.vnext > -INFINITY) {
+                if (cond_rank(m, S_m, b.vnext, 1)) {
+                    dir = 1;  // the next group still passes the test: grow
+                    lo = b.vnext;
+                    continue;
+                }
+                // In exact arithmetic every rank of a tie group passes or fails together; if rank 1
+                // of the next group failed only by rounding, later ranks of that group may pass,
+                // and the oracle counts them: look at that group once (rare).
+                if (!probe && near_rank(m, S_m, b.vnext)) {
+                    probe = true;
+                    lo = b.vnext;
+                    continue;
+                }
             }
             s_final = m;
             S_final = S_m;
