@@ -446,8 +446,9 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
 // NW = waves holding the row (1: a lane group of one wave; then G < 64 skips the candidate path).
-// cand: LDS, NW == 1: kCandCap floats private to this wave; NW > 1: NW*64 floats + NW ints.
-// list != null (NW == 1 only): the row's support list is wanted; returns true if it was written
+// cand: LDS, NW == 1: 2*kCandCap words private to this wave (values, columns); NW > 1: NW*64
+// floats + NW ints + NW*64 ints (values, counts, columns).
+// list != null: the row's support list is wanted; returns true if it was written
 // here (from the candidates), false if the caller has to scan the registers.
 template <int E, int NW, bool CAND, bool VEC, class Red>
 __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
@@ -510,7 +511,11 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
         } else {
             const int wave = threadIdx.x >> 6;
             int* cnt = reinterpret_cast<int*>(cand + NW * 64);
-            const int n_w = compact_candidates<E, VEC>(z, -1.0f, cand + wave * 64, 64, nullptr, 0, 0);
+            int* ccols = list ? cnt + NW : nullptr;   // NW*64 candidate columns after the counts
+            const int n_w = compact_candidates<E, VEC>(z, -1.0f, cand + wave * 64, 64,
+                                                       ccols ? ccols + wave * 64 : nullptr,
+                                                       VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
+                                                       VEC ? 256 * NW : 64 * NW);
             if (lane == 0) cnt[wave] = n_w;
             __syncthreads();
             int total = 0, worst = 0;
@@ -526,14 +531,18 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 for (int q = 0; q < kCandPerLane; ++q) {
                     const int idx = lane + 64 * q;
                     float v = -INFINITY;
-                    int pre = 0;
+                    int vc = 0, pre = 0;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
                         const int k = cnt[w];
-                        if (idx >= pre && idx < pre + k) v = cand[w * 64 + (idx - pre)];
+                        if (idx >= pre && idx < pre + k) {
+                            v = cand[w * 64 + (idx - pre)];
+                            if (ccols) vc = ccols[w * 64 + (idx - pre)];
+                        }
                         pre += k;
                     }
                     c[q] = v;
+                    cc[q] = vc;
                 }
             }
             __syncthreads();  // the lists are rewritten by the next row
@@ -541,11 +550,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
         if (fast) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers
             solve_core(c, wred, s_final, S_final);
-            if constexpr (NW == 1) {
-                if (list) {
-                    const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-                    emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap, live);
-                }
+            if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
+                const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+                emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,
+                                                            live && (NW == 1 || threadIdx.x < 64));
             }
         }
     }
@@ -913,7 +921,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
     int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
-    constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
     int64_t row = wave_row<G>(lane);
@@ -958,19 +965,20 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
     int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    __shared__ float cand[NW * 64 + NW];
+    __shared__ float cand[2 * NW * 64 + NW];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
         float z[E];
         load_row<E, VEC, FULL>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
         int s, n = 0;
         float t, h = 0.0f;
-        sparsemax_row<E, NW, true, VEC>(z, red, cand, s, t);
+        const bool listed = sparsemax_row<E, NW, true, VEC>(z, red, cand, s, t,
+                                                            cols ? cols + row * cap : nullptr, cap, true);
         if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
         store_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, z);
         if (threadIdx.x == 0) {
             supp[row] = s;
-            if (cols) cols[row * cap] = kColsOverflow;   // rows wider than a wave tile: no list
+            if (cols && !listed) cols[row * cap] = kColsOverflow;   // full-width search: no list
             if constexpr (EXTRA) {
                 if (nnz) nnz[row] = n;
                 if (tau) tau[row] = t;
@@ -998,7 +1006,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ supp,
     float* __restrict__ dx, int64_t R, int K)
 {
-    constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
     int64_t row = wave_row<G>(lane);
@@ -1027,7 +1034,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     const float* __restrict__ p, const int32_t* __restrict__ supp, float* __restrict__ dx, int64_t R,
     int K)
 {
-    constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
     int64_t row = wave_row<G>(lane);
@@ -1058,13 +1064,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     }
 }
 
+// Rows wider than one wave's tile (4096 < K <= 65536) with a support list: one wave per 4096-column
+// segment of a row.  Every wave of a row reads the whole list and gathers the same <= 64 values
+// (same fp64 sum in every wave), zero-fills its own segment and, once those stores are in the L2,
+// stores the values whose columns fall into it -- no synchronisation between the waves of a row.
+// Rows without a list are left to sparsemax_bwd_block_kernel (launched after this one).
+template <bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segment_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ cols, int cap,
+    const int32_t* __restrict__ supp, float* __restrict__ dx, int64_t R, int K, int nseg)
+{
+    constexpr int SEG = 4096;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (wid >= R * nseg) return;
+    const int64_t row = wid / nseg;
+    const int seg = (int)(wid - row * nseg);
+    const int c = lane < cap ? cols[row * cap + lane] : kColsNone;
+    if (__builtin_amdgcn_readfirstlane(c) == kColsOverflow) return;
+    float* dxrow = dx + row * K;
+    {
+        float zero[64];
+#pragma unroll
+        for (int e = 0; e < 64; ++e) zero[e] = 0.0f;
+        store_row<64, true, FULL>(dxrow + seg * SEG, K - seg * SEG, lane, 64, zero);
+    }
+    const float v = c >= 0 ? dy[row * K + c] : 0.0f;
+    WaveRed<64> red;
+    const double acc = red.sum((double)v);
+    const float mean = (float)acc / (float)supp[row];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c >= 0 && (c >> 12) == seg) dxrow[c] = v - mean;
+}
+
 template <int NW, int E, bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * NW) void sparsemax_bwd_block_kernel(
     const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ supp,
-    float* __restrict__ dx, int64_t R, int K)
+    float* __restrict__ dx, int64_t R, int K, const int32_t* __restrict__ cols, int cap)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        if (cols && cols[row * cap] != kColsOverflow) continue;   // done from its list (block-uniform)
         const int s = supp[row];   // block-uniform
         BlockRed<NW> red(lds);
         if (s <= kGatherMaxSupport) {
@@ -1153,8 +1195,19 @@ static void bwd_wave_go(const BwdArgs& a)
 template <int NW, int E, bool VEC, bool FULL>
 static void bwd_block_go(const BwdArgs& a)
 {
+    if (a.cols) {   // listed rows first, one wave per 4096-column segment
+        const int nseg = (a.K + 4095) / 4096;
+        const int64_t waves = a.R * nseg;
+        const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
+        if (a.K % 4096 == 0)
+            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true>), grid, dim3(64 * kWavesPerBlock),
+                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+        else
+            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<false>), grid, dim3(64 * kWavesPerBlock),
+                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+    }
     hipLaunchKernelGGL((sparsemax_bwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)),
-                       dim3(64 * NW), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
+                       dim3(64 * NW), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K, a.cols, a.cap);
 }
 
 // mode selection for one tile shape (A = lanes per row, or waves per row for the block kernels)
@@ -1264,7 +1317,9 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
-              K <= 4096 ? support_cols : nullptr, cap};   // wider rows have no lists (block kernels)
+              support_cols, cap};
+    // the segment kernel of the wide rows needs 16-byte accesses; otherwise everything goes by p
+    if (K > 4096 && !a.vec) a.cols = nullptr;
     SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }
