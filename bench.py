@@ -382,26 +382,37 @@ def main():
 
     if rank == 0 and not _dist_on() and not a.no_sweep:
         sweep = {}
-        for K, R, chunks in ((256, 1 << 20, 1), (65536, 1 << 15, 32)):
-            xs, dys = gen(R, K, a.sigma, dev, 99)
+
+        def adversarial(R, K):
+            """SURVEY.md 8(d) S1 adversarial rows, a quarter each: all equal (support K), one
+            dominant logit (support 1), an exact tie at the threshold, plain N(0,1)."""
+            xs, dys = gen(R, K, 1.0, dev, 99)
+            kind = torch.arange(R, device=dev) % 4
+            xs[kind == 0] = 0.25
+            xs[kind == 1] = -1.0
+            xs[kind == 1, 7 % K] = 3.0
+            xs[kind == 2] = -1.0
+            xs[kind == 2, 0] = 0.0
+            return xs, dys
+
+        def sweep_entry(tag, K, R, chunks, make):
+            xs, dys = make()
             w, fm, bm, ms_ = timed_sparsemax(native, xs, dys, max(3, a.steps // 4), 2, 1, dev)
             del xs, dys
             torch.cuda.empty_cache()
             gb = 20.0 * K * R / ((fm + bm) * 1e-3) / 1e9
-            sweep[f"K{K}"] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "fwd_ms": fm,
-                              "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
-                              "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
-        # the other logit distributions of SURVEY.md 8(d) S1 at the headline shape: wide supports
-        # (every element within 1 of the row maximum: full-width threshold search, streaming backward)
-        for tag, sg in (("K4096_sigma0.05", 0.05), ("K4096_sigma0.2", 0.2)):
-            xs, dys = gen(1 << 20, 4096, sg, dev, 99)
-            w, fm, bm, ms_ = timed_sparsemax(native, xs, dys, max(3, a.steps // 4), 2, 1, dev)
-            del xs, dys
-            torch.cuda.empty_cache()
-            gb = 20.0 * 4096 * (1 << 20) / ((fm + bm) * 1e-3) / 1e9
-            sweep[tag] = {"rows_per_launch": 1 << 20, "launches_per_1M_rows": 1, "fwd_ms": fm, "bwd_ms": bm,
-                          "rows_per_s": (1 << 20) / ((fm + bm) * 1e-3), "GBps": gb,
+            sweep[tag] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "fwd_ms": fm,
+                          "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
                           "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
+
+        # SURVEY.md 8(d) S1: K in {256, 4096, 65536} x {N(0,1), N(0,0.05^2), adversarial}; the
+        # headline line above is (4096, N(0,1)).  GBps is against the algorithmic 20 K bytes/row.
+        for K, R, chunks in ((256, 1 << 20, 1), (4096, 1 << 20, 1), (65536, 1 << 15, 32)):
+            if K != a.K or a.sigma != 1.0:
+                sweep_entry(f"K{K}", K, R, chunks, lambda: gen(R, K, 1.0, dev, 99))
+            sweep_entry(f"K{K}_sigma0.05", K, R, chunks, lambda: gen(R, K, 0.05, dev, 99))
+            sweep_entry(f"K{K}_adversarial", K, R, chunks, lambda: adversarial(R, K))
+        sweep_entry("K4096_sigma0.2", 4096, 1 << 20, 1, lambda: gen(1 << 20, 4096, 0.2, dev, 99))
         out["sweep"] = sweep
         out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, a.sigma),

@@ -408,6 +408,27 @@ constexpr int kLazyPasses = 8;
 constexpr int kLazyTry = 2 * kCandCap;      // attempt the compaction once |{z > tau_k}| is below this
 constexpr float kLazyMargin = 1e-3f;
 
+// The threshold of any SUBSET of a row is a lower bound of the row's threshold (more elements can
+// only raise tau).  One value per lane -- the lane's own maximum -- through a wave-local Michelot
+// iteration gives a bound that is already close for narrow distributions, at ~30 instructions a
+// step and no pass over the registers; it replaces the first full-width steps above.
+__device__ __forceinline__ float subset_bound(float v)
+{
+    WaveRed<64> wred;
+    float tau = -1.0f;
+    int cnt_prev = 0x7fffffff;
+    for (;;) {
+        const bool in = v > tau;
+        int c = in ? 1 : 0;
+        float sm = in ? v : 0.0f;
+        wred.cs(c, sm);
+        if (c >= cnt_prev) break;
+        cnt_prev = c;
+        tau = fmaxf(tau, (sm - 1.0f) / (float)c);
+    }
+    return tau;
+}
+
 // Support list of a row from Q candidates per lane (value c[q], column cc[q]): the non-zeros of p
 // are the candidates above tau.  One lane group of G lanes per row.  The lane that fills slot 0
 // is also the one that overwrites it with the overflow mark (same thread, program order).
@@ -458,7 +479,9 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
     float mx = z[0];
 #pragma unroll
     for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    float lane_mx = mx;
     mx = red.max(mx);
+    lane_mx -= mx;   // this lane's largest element in the shifted frame (-inf for padding lanes)
 #pragma unroll
     for (int e = 0; e < E; ++e) z[e] -= mx;
 
@@ -474,9 +497,12 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             const int colbase = VEC ? lane * 4 : lane, colstep = VEC ? 256 : 64;
             int n_c = compact_candidates<E, VEC>(z, -1.0f, cand, kCandCap, ccols, colbase, colstep);
             if (n_c > kCandCap) {
-                float tau = -1.0f;
+                float tau = subset_bound(lane_mx);
+                wave_lds_sync();
+                n_c = compact_candidates<E, VEC>(z, tau - kLazyMargin, cand, kCandCap, ccols, colbase,
+                                                 colstep);
                 int cnt_prev = 0x7fffffff;
-                for (int pass = 0; pass < kLazyPasses; ++pass) {
+                for (int pass = 0; n_c > kCandCap && pass < kLazyPasses; ++pass) {
                     int cn = 0;
                     float sm = 0.0f;
 #pragma unroll
@@ -512,40 +538,81 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             const int wave = threadIdx.x >> 6;
             int* cnt = reinterpret_cast<int*>(cand + NW * 64);
             int* ccols = list ? cnt + NW : nullptr;   // NW*64 candidate columns after the counts
-            const int n_w = compact_candidates<E, VEC>(z, -1.0f, cand + wave * 64, 64,
-                                                       ccols ? ccols + wave * 64 : nullptr,
-                                                       VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
-                                                       VEC ? 256 * NW : 64 * NW);
-            if (lane == 0) cnt[wave] = n_w;
-            __syncthreads();
-            int total = 0, worst = 0;
+            // candidates above thr = -1 first; if they do not fit (narrow logit distribution),
+            // block-wide Michelot steps raise the bound and the compaction is tried again above it
+            float thr = -1.0f, tau = -1.0f;
+            int cnt_prev = 0x7fffffff, passes = 0;
+            for (;;) {
+                const int n_w = compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
+                                                           ccols ? ccols + wave * 64 : nullptr,
+                                                           VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
+                                                           VEC ? 256 * NW : 64 * NW);
+                if (lane == 0) cnt[wave] = n_w;
+                __syncthreads();
+                int total = 0, worst = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const int k = cnt[w];
-                total += k;
-                worst = k > worst ? k : worst;
-            }
-            fast = worst <= 64 && total <= kCandCap;
-            if (fast) {
-#pragma unroll
-                for (int q = 0; q < kCandPerLane; ++q) {
-                    const int idx = lane + 64 * q;
-                    float v = -INFINITY;
-                    int vc = 0, pre = 0;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) {
-                        const int k = cnt[w];
-                        if (idx >= pre && idx < pre + k) {
-                            v = cand[w * 64 + (idx - pre)];
-                            if (ccols) vc = ccols[w * 64 + (idx - pre)];
-                        }
-                        pre += k;
-                    }
-                    c[q] = v;
-                    cc[q] = vc;
+                for (int w = 0; w < NW; ++w) {
+                    const int k = cnt[w];
+                    total += k;
+                    worst = k > worst ? k : worst;
                 }
+                fast = worst <= 64 && total <= kCandCap;
+                if (fast) {
+#pragma unroll
+                    for (int q = 0; q < kCandPerLane; ++q) {
+                        const int idx = lane + 64 * q;
+                        float v = -INFINITY;
+                        int vc = 0, pre = 0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            const int k = cnt[w];
+                            if (idx >= pre && idx < pre + k) {
+                                v = cand[w * 64 + (idx - pre)];
+                                if (ccols) vc = ccols[w * 64 + (idx - pre)];
+                            }
+                            pre += k;
+                        }
+                        c[q] = v;
+                        cc[q] = vc;
+                    }
+                }
+                __syncthreads();  // the lists are rewritten by the next attempt / the next row
+                if (fast) break;
+                if (thr == -1.0f) {   // first failure: the best wave-local subset bound, then retry
+                    tau = red.max(subset_bound(lane_mx));
+                    // ... refined on the subset of all 64 NW lane maxima (one value per lane: block
+                    // reductions, but no pass over the registers)
+                    for (int cp = 0x7fffffff;;) {
+                        const bool in = lane_mx > tau;
+                        int cn = in ? 1 : 0;
+                        float sm = in ? lane_mx : 0.0f;
+                        red.cs(cn, sm);
+                        if (cn >= cp) break;
+                        cp = cn;
+                        tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+                    }
+                    thr = tau - kLazyMargin;
+                    continue;
+                }
+                bool give_up = false;
+                for (;;) {   // block-uniform control flow: every value below comes out of red
+                    int cn = 0;
+                    float sm = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool in = z[e] > tau;
+                        cn += in ? 1 : 0;
+                        sm += in ? z[e] : 0.0f;
+                    }
+                    red.cs(cn, sm);
+                    if (cn >= cnt_prev || ++passes > kLazyPasses) { give_up = true; break; }
+                    cnt_prev = cn;
+                    tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+                    if (cn <= kLazyTry) break;
+                }
+                if (give_up) break;
+                thr = tau - kLazyMargin;
             }
-            __syncthreads();  // the lists are rewritten by the next row
         }
         if (fast) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers

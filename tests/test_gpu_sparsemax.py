@@ -216,7 +216,7 @@ def test_support_lists_and_list_backward(dev, oracle_mod, R, K, kind):
 
 
 @pytest.mark.parametrize("sigma", [0.3, 0.1, 0.05, 0.02, 0.005])
-@pytest.mark.parametrize("K", [1100, 2048, 3000, 4096])
+@pytest.mark.parametrize("K", [1100, 2048, 3000, 4096, 8192, 20000, 65536])
 def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     """Rows with more than 256 elements within 1 of the maximum: the forward raises the bound with
     full-width Michelot steps and compacts its candidates above (bound - 1e-3).  Half of the rows
@@ -227,7 +227,7 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     oracle's own fp32 test passes at isolated ranks deep inside the tie group by rounding, and its
     count-of-passing-ranks support size is not a prefix any more.)"""
     from lvmhelpers import _native
-    R = 256
+    R = 256 if K <= 4096 else 48
     rng = np.random.default_rng(int(1e4 * sigma) + K)
     x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
     _, s0, tau0, _ = oracle_mod.sparsemax_fwd(x)
@@ -262,7 +262,7 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
         nz = np.flatnonzero(p_ref[r] > 0)
         if nz.size > cap:
             assert c[r, 0] == -2
-        else:
+        elif K <= 4096 or c[r, 0] != -2:   # wide rows may keep no list (per-wave candidate limit)
             assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
     dx = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp).cpu().numpy()
     assert np.all(np.abs(dx - dx_ref) <= 1e-6 * np.abs(dy).max(axis=1, keepdims=True))
