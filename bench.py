@@ -236,7 +236,7 @@ def compaction_bench(native, dev, R, K, sigma, reps=5):
     support_compact and the weighted loss reduction, each against its algorithmic HBM bytes
     (count 4KR read; compact 4KR + 12N + 8(R+1); reduce 12N read)."""
     x, _ = gen(R, K, sigma, dev, 4321)
-    p, supp, nnz, _, _ = native.sparsemax_fwd(x, want_nnz=True)
+    p, supp, nnz, _, _, lists = native.sparsemax_fwd(x, want_nnz=True, want_cols=True)
     del x
 
     def timeit(fn):
@@ -258,7 +258,15 @@ def compaction_bench(native, dev, R, K, sigma, reps=5):
     t_red = timeit(lambda: native.weighted_loss_reduce_fwd(vals, comps, off, 1.0 / R))
     t_compact = max(t_all - t_off, 1e-6)
     gb = lambda b, ms: b / (ms * 1e-3) / 1e9
+    # the same from the forward's support lists: count + offsets + sync + compact, no pass over p
+    t_lists = timeit(lambda: native.support_compact(p, support_cols=lists))
+    fused_bytes = 12.0 * N + 8.0 * (R + 1) + 2 * 4.0 * lists.shape[1] * R
     return {"R": R, "K": K, "N": N,
+            "from_support_lists": {"ms_count_offsets_compact": t_lists,
+                                   "ms_scan_count_offsets_compact": t_count + t_all,
+                                   "algorithmic_bytes": fused_bytes,
+                                   "note": "what the Marginalizer / top-k paths run: rows listed by the "
+                                           "forward are counted and compacted from <= cap entries"},
             "support_count": {"ms": t_count, "GBps": gb(4.0 * K * R, t_count)},
             "support_offsets": {"ms": t_off},
             "support_compact": {"ms": t_compact, "GBps": gb(4.0 * K * R + 12.0 * N + 8.0 * (R + 1), t_compact),

@@ -97,6 +97,16 @@ int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, int64_t R, v
                           size_t workspace_bytes, void* stream);
 int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows, int32_t* cols,
                           float* vals, int64_t R, int32_t K, void* stream);
+/* The same two steps from the forward's support lists (smlvm_sparsemax_fwd_cols): rows that have
+ * a list are counted / compacted from its <= cap entries (sorted by column on the fly, so the
+ * output order is unchanged) and only gather their probabilities; rows marked -2 are scanned.
+ * This is the "fused into the sparsemax epilogue" form of the reference's boolean-mask compaction
+ * (lvmhelpers/structmarg.py:113-126): 12 N + 4 cap R bytes instead of 4 K R + 12 N. */
+int smlvm_support_count_cols(const float* p, const int32_t* support_cols, int32_t cap, int32_t* nnz,
+                             int64_t R, int32_t K, void* stream);
+int smlvm_support_compact_cols(const float* p, const int32_t* support_cols, int32_t cap,
+                               const int64_t* row_offsets, int32_t* rows, int32_t* cols, float* vals,
+                               int64_t R, int32_t K, void* stream);
 size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N);
 int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps, const int64_t* row_offsets,
                                    float* row_out, float* total, float inv_b, int64_t R, int64_t N,

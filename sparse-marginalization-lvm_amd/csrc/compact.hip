@@ -19,14 +19,26 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
 }
 
 // ------------------------------------------------------------------------------- count
+// lists (optional): the forward's support lists (include/sparsemarg.h, smlvm_sparsemax_fwd_cols);
+// a row that has one is counted / compacted from its <= cap entries without touching its K
+// probabilities, a row marked -2 is scanned as before.
 template <bool VEC>
 __global__ __launch_bounds__(256) void support_count_kernel(const float* __restrict__ p,
+                                                            const int32_t* __restrict__ lists, int cap,
                                                             int32_t* __restrict__ nnz, int64_t R,
                                                             int K)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
+    if (lists) {
+        const int cl = lane < cap ? lists[row * cap + lane] : -1;
+        if (__builtin_amdgcn_readfirstlane(cl) != -2) {   // wave-uniform
+            const int n = __popcll(__ballot(cl >= 0));
+            if (lane == 0) nnz[row] = n;
+            return;
+        }
+    }
     const float* pr = p + row * K;
     int c = 0;
     if constexpr (VEC) {
@@ -131,7 +143,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 // ------------------------------------------------------------------------------- compact
 template <bool VEC>
 __global__ __launch_bounds__(256) void support_compact_kernel(
-    const float* __restrict__ p, const int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows,
+    const float* __restrict__ p, const int32_t* __restrict__ lists, int cap,
+    const int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows,
     int32_t* __restrict__ cols, float* __restrict__ vals, int64_t R, int K)
 {
     const int lane = threadIdx.x & 63;
@@ -139,6 +152,22 @@ __global__ __launch_bounds__(256) void support_compact_kernel(
     if (row >= R) return;
     const float* pr = p + row * K;
     int64_t out = row_offsets[row];
+    if (lists) {
+        const int cl = lane < cap ? lists[row * cap + lane] : -1;
+        if (__builtin_amdgcn_readfirstlane(cl) != -2) {   // wave-uniform
+            // the list is in no particular order: a lane's output slot is the rank of its column
+            const int n = __popcll(__ballot(cl >= 0));
+            int rank = 0;
+            for (int k = 0; k < n; ++k) rank += __builtin_amdgcn_readlane(cl, k) < cl ? 1 : 0;
+            if (cl >= 0) {
+                const int64_t pos = out + rank;
+                if (rows) rows[pos] = (int32_t)row;
+                if (cols) cols[pos] = cl;
+                if (vals) vals[pos] = pr[cl];
+            }
+            return;
+        }
+    }
     if constexpr (VEC) {
         const float4* p4 = reinterpret_cast<const float4*>(pr);
         const int K4 = K >> 2;
@@ -265,17 +294,30 @@ __global__ __launch_bounds__(256) void unpack_configs_kernel(const uint32_t* __r
 
 using namespace smlvm;
 
-extern "C" int smlvm_support_count(const float* p, int32_t* nnz, int64_t R, int32_t K, void* stream)
+static int support_count_go(const float* p, const int32_t* lists, int32_t cap, int32_t* nnz,
+                            int64_t R, int32_t K, void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (lists && (cap < 1 || cap > 64)) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!p || !nnz) return SMLVM_ERR_INVALID;
     const unsigned grid = (unsigned)((R + 3) / 4);
     if (K % 4 == 0 && aligned16(p))
-        hipLaunchKernelGGL(support_count_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, nnz, R, K);
+        hipLaunchKernelGGL(support_count_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, nnz, R, K);
     else
-        hipLaunchKernelGGL(support_count_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, nnz, R, K);
+        hipLaunchKernelGGL(support_count_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, nnz, R, K);
     return check_launch();
+}
+
+extern "C" int smlvm_support_count(const float* p, int32_t* nnz, int64_t R, int32_t K, void* stream)
+{
+    return support_count_go(p, nullptr, 0, nnz, R, K, stream);
+}
+
+extern "C" int smlvm_support_count_cols(const float* p, const int32_t* support_cols, int32_t cap,
+                                        int32_t* nnz, int64_t R, int32_t K, void* stream)
+{
+    return support_count_go(p, support_cols, cap, nnz, R, K, stream);
 }
 
 extern "C" size_t smlvm_support_offsets_workspace_bytes(int64_t R)
@@ -304,18 +346,33 @@ extern "C" int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, i
     return check_launch();
 }
 
-extern "C" int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows,
-                                     int32_t* cols, float* vals, int64_t R, int32_t K, void* stream)
+static int support_compact_go(const float* p, const int32_t* lists, int32_t cap,
+                              const int64_t* row_offsets, int32_t* rows, int32_t* cols, float* vals,
+                              int64_t R, int32_t K, void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (lists && (cap < 1 || cap > 64)) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!p || !row_offsets) return SMLVM_ERR_INVALID;
     const unsigned grid = (unsigned)((R + 3) / 4);
     if (K % 4 == 0 && aligned16(p))
-        hipLaunchKernelGGL(support_compact_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, row_offsets, rows, cols, vals, R, K);
+        hipLaunchKernelGGL(support_compact_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, row_offsets, rows, cols, vals, R, K);
     else
-        hipLaunchKernelGGL(support_compact_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, row_offsets, rows, cols, vals, R, K);
+        hipLaunchKernelGGL(support_compact_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, row_offsets, rows, cols, vals, R, K);
     return check_launch();
+}
+
+extern "C" int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows,
+                                     int32_t* cols, float* vals, int64_t R, int32_t K, void* stream)
+{
+    return support_compact_go(p, nullptr, 0, row_offsets, rows, cols, vals, R, K, stream);
+}
+
+extern "C" int smlvm_support_compact_cols(const float* p, const int32_t* support_cols, int32_t cap,
+                                          const int64_t* row_offsets, int32_t* rows, int32_t* cols,
+                                          float* vals, int64_t R, int32_t K, void* stream)
+{
+    return support_compact_go(p, support_cols, cap, row_offsets, rows, cols, vals, R, K, stream);
 }
 
 extern "C" size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N)

@@ -19,7 +19,8 @@ ABI_SYMBOLS = [
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
-    "smlvm_support_compact", "smlvm_weighted_loss_reduce_workspace_bytes",
+    "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
+    "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
     "smlvm_sparsemap_bwd",
@@ -173,15 +174,31 @@ def support_offsets(nnz):
     return off
 
 
-def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True):
+def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None):
     """Row-major (rows, cols, vals) lists of the positive entries of p [R,K] plus row_offsets.
 
+    support_cols: the forward's support lists for this very p (`sparsemax_fwd(..., want_cols=True)`,
+    or `functional.support_cols_of(p)`): rows that have a list are counted and compacted from it
+    instead of from their K probabilities; the output is the same.
     One host sync (reading N = row_offsets[R]) to size the outputs.
     """
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
+    cap = 0
+    if support_cols is not None:
+        support_cols = _need_gpu(support_cols, torch.int32, "support_cols")
+        if support_cols.dim() != 2 or support_cols.shape[0] != R:
+            raise ValueError("support_cols must be [R, cap]")
+        cap = support_cols.shape[1]
     if nnz is None:
-        nnz = support_count(p)
+        if support_cols is None:
+            nnz = support_count(p)
+        else:
+            nnz = torch.empty(R, dtype=torch.int32, device=p.device)
+            with torch.cuda.device(p.device):
+                _check(lib().smlvm_support_count_cols(_p(p), _p(support_cols), _i32(cap), _p(nnz),
+                                                      _i64(R), _i32(K), _stream()),
+                       "smlvm_support_count_cols")
     off = support_offsets(nnz)
     N = int(off[R].item())
     dev = p.device
@@ -189,8 +206,13 @@ def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True)
     cols = torch.empty(N, dtype=torch.int32, device=dev) if want_cols else None
     vals = torch.empty(N, dtype=torch.float32, device=dev) if want_vals else None
     with torch.cuda.device(dev):
-        _check(lib().smlvm_support_compact(_p(p), _p(off), _p(rows), _p(cols), _p(vals), _i64(R),
-                                           _i32(K), _stream()), "smlvm_support_compact")
+        if support_cols is None:
+            _check(lib().smlvm_support_compact(_p(p), _p(off), _p(rows), _p(cols), _p(vals), _i64(R),
+                                               _i32(K), _stream()), "smlvm_support_compact")
+        else:
+            _check(lib().smlvm_support_compact_cols(_p(p), _p(support_cols), _i32(cap), _p(off),
+                                                    _p(rows), _p(cols), _p(vals), _i64(R), _i32(K),
+                                                    _stream()), "smlvm_support_compact_cols")
     return off, rows, cols, vals
 
 

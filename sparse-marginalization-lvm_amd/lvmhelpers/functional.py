@@ -12,10 +12,11 @@ class _Sparsemax(torch.autograd.Function):
         shape = x.shape
         p, supp, _, _, _, cols = _native.sparsemax_fwd(x.reshape(-1, shape[-1]), want_cols=True)
         ctx.save_for_backward(p, supp, cols)
-        return p.view(shape)
+        ctx.mark_non_differentiable(cols)
+        return p.view(shape), cols
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dcols=None):
         p, supp, cols = ctx.saved_tensors
         dx = _native.sparsemax_bwd_cols(dy.reshape(p.shape).contiguous(), cols, p, supp)
         return dx.view(dy.shape)
@@ -28,11 +29,11 @@ class _SparsemaxEntropy(torch.autograd.Function):
     def forward(ctx, x):
         p, supp, _, _, ent, cols = _native.sparsemax_fwd(x, want_entropy=True, want_cols=True)
         ctx.save_for_backward(p, supp, cols)
-        ctx.mark_non_differentiable(supp)
-        return p, ent, supp
+        ctx.mark_non_differentiable(supp, cols)
+        return p, ent, supp, cols
 
     @staticmethod
-    def backward(ctx, dp, dent, _dsupp):
+    def backward(ctx, dp, dent, _dsupp, _dcols=None):
         p, supp, cols = ctx.saved_tensors
         if dp is None and dent is None:
             return torch.zeros_like(p)
@@ -136,13 +137,35 @@ def sparsemax(X, dim=-1):
     if dim < 0:
         dim += X.dim()
     if dim != X.dim() - 1:
-        return _Sparsemax.apply(X.transpose(dim, -1).contiguous()).transpose(dim, -1)
-    return _Sparsemax.apply(X.contiguous())
+        return _Sparsemax.apply(X.transpose(dim, -1).contiguous())[0].transpose(dim, -1)
+    p, cols = _Sparsemax.apply(X.contiguous())
+    if p.dim() == 2:
+        _tag_support(p, cols)
+    return p
+
+
+SUPPORT_ATTR = "_smlvm_support_cols"
+
+
+def _tag_support(p, cols):
+    """Hang the forward's support lists on the probability tensor itself, so that a later
+    `_native.support_compact(p.detach(), support_cols=support_cols_of(p))` does not have to scan p
+    again.  The tag lives on this tensor object only (views, detach() and arithmetic drop it)."""
+    setattr(p, SUPPORT_ATTR, cols)
+
+
+def support_cols_of(p):
+    cols = getattr(p, SUPPORT_ATTR, None)
+    if cols is not None and (p.dim() != 2 or cols.shape[0] != p.shape[0]):
+        return None
+    return cols
 
 
 def sparsemax_with_entropy(X):
     """X [B,K] -> (p [B,K], entropy [B], supp_size [B] int32)."""
-    return _SparsemaxEntropy.apply(X.contiguous())
+    p, ent, supp, cols = _SparsemaxEntropy.apply(X.contiguous())
+    _tag_support(p, cols)
+    return p, ent, supp
 
 
 def entropy(p):

@@ -91,7 +91,8 @@ class Marginalizer(torch.nn.Module):
     def _forward_compact(self, encoder_input, decoder_input, labels, discrete_latent_z,
                          encoder_probs, encoder_entropy):
         batch_size, latent_size = encoder_probs.shape
-        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False)
+        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False,
+                                                      support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         if rows_l.numel() == 0:
             raise RuntimeError("Marginalizer: the encoder distribution has no live category")

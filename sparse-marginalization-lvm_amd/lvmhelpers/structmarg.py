@@ -73,7 +73,8 @@ class TopKSparsemaxMarg(torch.nn.Module):
         entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
 
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
-        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False)
+        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False,
+                                                      support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         encoder_input_sel = encoder_input[rows_l]
         decoder_input_sel = decoder_input[rows_l]
@@ -127,7 +128,7 @@ class SparseMAPWrapper(nn.Module):
         p, aset_bits, alen, _, _ = F_.sparsemap_batched(
             scores, init_scores, self.budget, self.max_iter)
 
-        off, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False)
+        off, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, support_cols=F_.support_cols_of(p))
         support = (off[1:] - off[:-1]).tolist()
         assert min(support) > 0
         rows_l = rows.long()

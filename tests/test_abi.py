@@ -71,6 +71,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(0), null) == 0
     assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(3), null) == -1
     assert lib.smlvm_support_compact(null, null, null, null, null, i64(3), i32(4), null) == -1
+    assert lib.smlvm_support_compact_cols(null, null, i32(0), null, null, null, null, i64(0), i32(4), null) == 0
+    assert lib.smlvm_support_compact_cols(one, one, i32(65), one, null, null, null, i64(3), i32(4), null) == -1
+    assert lib.smlvm_support_count_cols(one, one, i32(0), one, i64(3), i32(4), null) == -1
+    assert lib.smlvm_support_count_cols(null, null, i32(0), null, i64(3), i32(4), null) == -1
     lib.smlvm_support_offsets_workspace_bytes.restype = ctypes.c_size_t
     lib.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
     assert lib.smlvm_support_offsets_workspace_bytes(1 << 20) == 8 * 512

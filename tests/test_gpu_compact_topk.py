@@ -99,3 +99,30 @@ def test_pbinary_topk_host_api(dev, oracle_mod):
     assert np.array_equal(cfg, oracle_mod.binary_topk_batched(scores, 10)[0])
     with pytest.raises(ValueError):
         pbinary_topk.batched_topk(scores.astype(np.float64), cfg, 10)
+
+
+@pytest.mark.parametrize("R,K,sigma", [(64, 10, 1.0), (64, 256, 1.0), (300, 1000, 1.0), (64, 4096, 1.0),
+                                       (64, 4096, 0.05), (20, 8192, 1.0), (9, 65536, 1.0),
+                                       (128, 256, 0.05)])
+def test_compact_from_support_lists(dev, R, K, sigma):
+    """The compaction fed with the forward's support lists (rows with a list never read their K
+    probabilities; rows marked -2 are scanned) must equal the scan of p: same offsets, and rows /
+    cols / vals in the row-major order of torch.nonzero(p > 0)."""
+    from lvmhelpers import _native, functional as F_
+    g = torch.Generator(device=dev).manual_seed(R + K)
+    x = torch.empty(R, K, device=dev).normal_(0.0, sigma, generator=g)
+    p, _, nnz, _, _, lists = _native.sparsemax_fwd(x, want_nnz=True, want_cols=True)
+    off0, rows0, cols0, vals0 = _native.support_compact(p)
+    off1, rows1, cols1, vals1 = _native.support_compact(p, support_cols=lists)
+    assert torch.equal(off0, off1) and torch.equal(rows0, rows1)
+    assert torch.equal(cols0, cols1) and torch.equal(vals0, vals1)
+    nz = torch.nonzero(p > 0)
+    assert torch.equal(rows1.long(), nz[:, 0]) and torch.equal(cols1.long(), nz[:, 1])
+    assert torch.equal((off1[1:] - off1[:-1]).to(torch.int32), nnz)
+    # the autograd wrappers tag their output with the lists
+    q = F_.sparsemax(x.clone().requires_grad_(True))
+    tagged = F_.support_cols_of(q)
+    assert tagged is not None and torch.equal(tagged, lists)
+    assert F_.support_cols_of(q.detach()) is None and F_.support_cols_of(q * 1.0) is None
+    q2, _, _ = F_.sparsemax_with_entropy(x)
+    assert torch.equal(F_.support_cols_of(q2), lists)
