@@ -193,11 +193,16 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dx_kernel(
     }
 }
 
-constexpr int kDwTile = 64;       // (row, feature) pairs staged per step (even)
+constexpr int kDwTile = 256;      // (row, feature) pairs staged per step (even)
 constexpr int kDwMaxBlocks = 2048;
 
-// dW[c, r] = sum_p g_p (softmax_pc - [c == y_p]) x_pr, db[c] likewise with x = 1: thread = class,
-// (row, feature) pairs two at a time from an LDS tile stored [r][pair] so a pair is one ds_read_b64.
+// dW[c, r] = sum_p g_p (softmax_pc - [c == y_p]) x_pr, db[c] likewise with x = 1.  Lane l of every
+// wave owns the classes l, l + 64, l + 128, l + 192; the four waves of a block split the (row,
+// feature) pairs of a tile between them, two pairs per step from an LDS tile stored [r][pair] (a
+// pair is one broadcast ds_read_b64).  With thread = one class and every wave reading every pair
+// (the first version) the LDS return path was the bound -- 32 B x 64 lanes x 4 waves per pair;
+// now each pair is read by one wave.  The waves' accumulators are folded through LDS in wave order.
+constexpr int kDwCls = 4;   // classes per lane: C <= 256
 template <int R, typename YT>
 __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
@@ -208,16 +213,21 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
     __shared__ __align__(8) float ls[kDwTile];
     __shared__ __align__(8) float gs[kDwTile];
     __shared__ __align__(8) int ys[kDwTile];
-    const int c = threadIdx.x;
-    const bool mine = c < C;
-    float w[R];
-    f32x2 acc[R + 1];
-    float bc = 0.0f;
+    __shared__ float fold[3][kDwCls * 64 * (R + 1)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float w[kDwCls][R], bc[kDwCls];
+    f32x2 acc[kDwCls][R + 1];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { w[r] = mine ? W[c * R + r] : 0.0f; acc[r] = splat(0.0f); }
-    acc[R] = splat(0.0f);
-    if (mine) bc = b[c];
+    for (int k = 0; k < kDwCls; ++k) {
+        const int c = lane + 64 * k;
+        bc[k] = c < C ? b[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { w[k][r] = c < C ? W[c * R + r] : 0.0f; acc[k][r] = splat(0.0f); }
+        acc[k][R] = splat(0.0f);
+    }
     const f32x2 k2 = splat(kLog2e);
+    constexpr int kPerWave = kDwTile / 4;
     const int64_t tiles = (P + kDwTile - 1) / kDwTile;
     for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const int64_t p0 = t * kDwTile;
@@ -236,30 +246,55 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
         }
         __syncthreads();
 #pragma unroll 2
-        for (int i = 0; i < kDwTile; i += 2) {
+        for (int ii = 0; ii < kPerWave; ii += 2) {
+            const int i = wave * kPerWave + ii;
             f32x2 xr[R];
-            f32x2 l = splat(bc);
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                xr[r] = *reinterpret_cast<const f32x2*>(&xs[r * kDwTile + i]);
-                l = fma2(xr[r], splat(w[r]), l);
-            }
+            for (int r = 0; r < R; ++r) xr[r] = *reinterpret_cast<const f32x2*>(&xs[r * kDwTile + i]);
             const f32x2 lz = *reinterpret_cast<const f32x2*>(&ls[i]);
             const f32x2 g = *reinterpret_cast<const f32x2*>(&gs[i]);
             const int y0 = ys[i], y1 = ys[i + 1];
-            const f32x2 tt = fma2(l, k2, -lz);
-            const f32x2 pr = {ex2(tt.x), ex2(tt.y)};
-            f32x2 hot = {(c == y0) ? 1.0f : 0.0f, (c == y1) ? 1.0f : 0.0f};
-            const f32x2 dl = g * (pr - hot);
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[r] = fma2(dl, xr[r], acc[r]);
-            acc[R] += dl;
+            for (int k = 0; k < kDwCls; ++k) {
+                const int c = lane + 64 * k;
+                f32x2 l = splat(bc[k]);
+#pragma unroll
+                for (int r = 0; r < R; ++r) l = fma2(xr[r], splat(w[k][r]), l);
+                const f32x2 tt = fma2(l, k2, -lz);
+                const f32x2 pr = {ex2(tt.x), ex2(tt.y)};
+                const f32x2 hot = {(c == y0) ? 1.0f : 0.0f, (c == y1) ? 1.0f : 0.0f};
+                const f32x2 dl = g * (pr - hot);
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[k][r] = fma2(dl, xr[r], acc[k][r]);
+                acc[k][R] += dl;
+            }
         }
     }
-    if (mine) {
-        float* o = partial + ((int64_t)blockIdx.x * C + c) * (R + 1);
+    // fold the four waves: waves 1..3 park their sums, wave 0 adds them in wave order
+    __syncthreads();
+    if (wave > 0) {
 #pragma unroll
-        for (int r = 0; r <= R; ++r) o[r] = acc[r].x + acc[r].y;
+        for (int k = 0; k < kDwCls; ++k)
+#pragma unroll
+            for (int r = 0; r <= R; ++r)
+                fold[wave - 1][(k * (R + 1) + r) * 64 + lane] = acc[k][r].x + acc[k][r].y;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < kDwCls; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                float* o = partial + ((int64_t)blockIdx.x * C + c) * (R + 1);
+#pragma unroll
+                for (int r = 0; r <= R; ++r) {
+                    float v = acc[k][r].x + acc[k][r].y;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) v += fold[q][(k * (R + 1) + r) * 64 + lane];
+                    o[r] = v;
+                }
+            }
+        }
     }
 }
 
