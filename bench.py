@@ -198,6 +198,37 @@ def sparsemap_cpu_baseline(B, n, budget, sigma):
                       f"oracle/sparsemap_oracle.c forward, {t:.1f} s on 1 of {os.cpu_count()} host cores"}
 
 
+def topk_bench(native, dev, B, n, k, reps=20, cpu=True):
+    """k-best bit vectors of N(0,1) scores, one launch for the batch; next to it
+    the reference's own binary_topk.h compiled in place (oracle/_ref, 1 thread) when that build
+    travelled with the tree, else our C restatement of it."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(B, n, device=dev, generator=g)
+    native.binary_topk_batched(x, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        native.binary_topk_batched(x, k)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out = {"B": B, "bits": n, "k": k, "ms": ms, "samples_per_s": B / (ms * 1e-3),
+           "note": "includes the allocation of the [B,k,n] fp32 output by the Python wrapper"}
+    if cpu:
+        import oracle
+        xs = x[:min(B, 2048)].cpu().numpy()
+        kind, fn = "port", oracle.binary_topk_batched
+        if oracle.ref_lib() is not None:
+            kind, fn = "reference", oracle.ref_binary_topk_batched
+        t0 = time.perf_counter()
+        fn(xs, k)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": xs.shape[0] / t, "unit": "samples/s", "cores": 1, "kind": kind,
+                               "sample": f"{xs.shape[0]} samples, {t * 1e3:.1f} ms on 1 host core"}
+    return out
+
+
 def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
     g = torch.Generator(device=dev).manual_seed(seed)
     x = torch.randn(B, n, device=dev, generator=g) * sigma
@@ -425,6 +456,9 @@ def main():
         out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, 0.05)]
+        out["binary_topk"] = [topk_bench(native, dev, 64, 32, 10, cpu=not a.no_cpu),
+                              topk_bench(native, dev, 64, 128, 10, cpu=not a.no_cpu),
+                              topk_bench(native, dev, 8192, 128, 10, cpu=not a.no_cpu)]
         out["sparsemap"] = [sparsemap_bench(native, dev, 64, 32, 0, 1.0),
                             sparsemap_bench(native, dev, 64, 32, 16, 1.0),
                             sparsemap_bench(native, dev, 1024, 128, 0, 1.0),
