@@ -749,7 +749,17 @@ __device__ __forceinline__ void nt_store4(float4* p, float4 v)
 // Lane `gl` of a group of GT lanes owns, for chunk i, the float4 with index i*GT + gl (VEC) or
 // the element i*GT + gl (scalar): every load/store instruction covers consecutive addresses.
 // FULL: K equals the tile capacity GT*E, so no bounds predicates are needed.
-template <int E, bool VEC, bool FULL>
+// UNI (rows that are not 16-byte addressable only): `row` is wave-uniform, so the scalar-layout
+// accesses go through a raw buffer resource of K*4 bytes -- the hardware drops out-of-range lanes
+// (loads return 0, stores vanish), which removes the per-element branches (each conditional load
+// used to get its own s_waitcnt vmcnt(0)) and the per-element 64-bit addresses (the 1024-thread
+// kernels spilled 140 registers on them): one 32-bit offset per access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* row, int K)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, K * 4, 0x00020000);
+}
+
+template <int E, bool VEC, bool FULL, bool UNI = false>
 __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, int gl, int GT,
                                          float (&z)[E], float pad)
 {
@@ -764,6 +774,18 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, i
             if (FULL || f < K4) v = nt_load4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl));
             z[4 * i + 0] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
         }
+    } else if constexpr (UNI) {
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(row, K);
+        // opaque copy of the lane index: keeps the 64 offsets and 64 lane masks derived from it
+        // from being hoisted out of the kernel's row loop (and spilled); they cost one
+        // instruction each where they are used
+        asm volatile("" : "+v"(gl));
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int c = e * GT + gl;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, c * 4, 0, 0));
+            z[e] = (c < K) ? v : pad;
+        }
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -773,7 +795,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, i
     }
 }
 
-template <int E, bool VEC, bool FULL>
+template <int E, bool VEC, bool FULL, bool UNI = false>
 __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl, int GT,
                                           const float (&z)[E])
 {
@@ -787,6 +809,12 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
                 nt_store4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl),
                           make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]));
         }
+    } else if constexpr (UNI) {
+        const __amdgpu_buffer_rsrc_t rs = row_rsrc(row, K);
+        asm volatile("" : "+v"(gl));
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z[e]), rs, (e * GT + gl) * 4, 0, 0);
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -1035,14 +1063,14 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
     __shared__ float cand[2 * NW * 64 + NW];
     for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
         float z[E];
-        load_row<E, VEC, FULL>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
+        load_row<E, VEC, FULL, true>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
         int s, n = 0;
         float t, h = 0.0f;
         const bool listed = sparsemax_row<E, NW, true, VEC>(z, red, cand, s, t,
                                                             cols ? cols + row * cap : nullptr, cap, true);
         if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
-        store_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, z);
+        store_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, z);
         if (threadIdx.x == 0) {
             supp[row] = s;
             if (cols && !listed) cols[row * cap] = kColsOverflow;   // full-width search: no list
@@ -1178,15 +1206,15 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_bwd_block_kernel(
         BlockRed<NW> red(lds);
         if (s <= kGatherMaxSupport) {
             float a[E];
-            load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, a, 0.0f);
+            load_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, a, 0.0f);
             bwd_row_gather<E, VEC>(dy + row * K, threadIdx.x, 64 * NW, a, s, red);
-            store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, a);
+            store_row<E, VEC, FULL, true>(dx + row * K, K, threadIdx.x, 64 * NW, a);
         } else {
             float g[E], pv[E];
-            load_row<E, VEC, FULL>(p + row * K, K, threadIdx.x, 64 * NW, pv, 0.0f);
-            load_row<E, VEC, FULL>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
+            load_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, pv, 0.0f);
+            load_row<E, VEC, FULL, true>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
             bwd_row(g, pv, s, red);
-            store_row<E, VEC, FULL>(dx + row * K, K, threadIdx.x, 64 * NW, g);
+            store_row<E, VEC, FULL, true>(dx + row * K, K, threadIdx.x, 64 * NW, g);
         }
         __syncthreads();
     }
