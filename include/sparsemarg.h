@@ -62,9 +62,8 @@ int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_siz
  *   unused slots; first entry -2 = no list for this row (more than cap non-zeros, or a row whose
  *   threshold search could not run on a candidate list: more than 256 elements within 1 of the row
  *   maximum after the bound has been raised; for K > 4096 more than 64 of them in one wave's 64 E
- *   columns): the backward then reads p for that row exactly like smlvm_sparsemax_bwd.  Rows with
- *   K > 4096 use their lists only with 16-byte aligned tensors and K % 4 == 0.  support_cols may
- *   be NULL (then these are the plain entry points). */
+ *   columns): the backward then reads p for that row exactly like smlvm_sparsemax_bwd.
+ *   support_cols may be NULL (then these are the plain entry points). */
 int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
                              float* entropy, int32_t* support_cols, int32_t cap, int64_t R,
                              int32_t K, void* stream);

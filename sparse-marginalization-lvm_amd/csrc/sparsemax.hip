@@ -1164,7 +1164,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
 // (same fp64 sum in every wave), zero-fills its own segment and, once those stores are in the L2,
 // stores the values whose columns fall into it -- no synchronisation between the waves of a row.
 // Rows without a list are left to sparsemax_bwd_block_kernel (launched after this one).
-template <bool FULL>
+template <bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segment_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ cols, int cap,
     const int32_t* __restrict__ supp, float* __restrict__ dx, int64_t R, int K, int nseg)
@@ -1183,7 +1183,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segmen
         float zero[64];
 #pragma unroll
         for (int e = 0; e < 64; ++e) zero[e] = 0.0f;
-        store_row<64, true, FULL>(dxrow + seg * SEG, K - seg * SEG, lane, 64, zero);
+        if constexpr (VEC) {
+            store_row<64, true, FULL>(dxrow + seg * SEG, K - seg * SEG, lane, 64, zero);
+        } else {   // rows that are not 16-byte addressable: range-checked dword stores
+            const __amdgpu_buffer_rsrc_t rs = row_rsrc(dxrow, K);
+#pragma unroll
+            for (int e = 0; e < 64; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(0, rs, (seg * SEG + e * 64 + lane) * 4, 0, 0);
+        }
     }
     const float v = c >= 0 ? dy[row * K + c] : 0.0f;
     WaveRed<64> red;
@@ -1294,11 +1301,14 @@ static void bwd_block_go(const BwdArgs& a)
         const int nseg = (a.K + 4095) / 4096;
         const int64_t waves = a.R * nseg;
         const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
-        if (a.K % 4096 == 0)
-            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true>), grid, dim3(64 * kWavesPerBlock),
+        if (!a.vec)
+            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<false, false>), grid, dim3(64 * kWavesPerBlock),
+                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+        else if (a.K % 4096 == 0)
+            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, true>), grid, dim3(64 * kWavesPerBlock),
                                0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
         else
-            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<false>), grid, dim3(64 * kWavesPerBlock),
+            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, false>), grid, dim3(64 * kWavesPerBlock),
                                0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
     }
     hipLaunchKernelGGL((sparsemax_bwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)),
@@ -1413,8 +1423,6 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
               support_cols, cap};
-    // the segment kernel of the wide rows needs 16-byte accesses; otherwise everything goes by p
-    if (K > 4096 && !a.vec) a.cols = nullptr;
     SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }

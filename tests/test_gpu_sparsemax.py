@@ -269,3 +269,34 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     # without the lists (different kernel instantiation of the same search)
     p2, supp2, _, _, _ = _native.sparsemax_fwd(xt)
     assert np.array_equal(p2.cpu().numpy(), p_ref) and np.array_equal(supp2.cpu().numpy(), s_ref)
+
+
+@pytest.mark.parametrize("R,K", [(6, 5000), (5, 8192), (4, 50001), (7, 4097), (9, 3001), (64, 255)])
+def test_list_pair_on_rows_that_are_not_16_byte_addressable(dev, oracle_mod, R, K):
+    """Odd K and/or a base pointer off by one float: the scalar-layout kernels (raw buffer accesses
+    with hardware range checking for K > 4096) must give the same lists, p and dx."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(31 * R + K)
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+
+    def off_by_one(a):   # same values in a buffer whose rows start 4 bytes off a 16-byte boundary
+        buf = torch.empty(a.size + 1, dtype=torch.float32, device=dev)
+        v = buf[1:].view(a.shape)
+        v.copy_(torch.from_numpy(a))
+        assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+        return v
+
+    xt, dyt = off_by_one(x), off_by_one(dy)
+    p, supp, _, _, _, cols = _native.sparsemax_fwd(xt, want_cols=True)
+    assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(supp.cpu().numpy(), s_ref)
+    c = cols.cpu().numpy()
+    for r in range(R):
+        nz = np.flatnonzero(p_ref[r] > 0)
+        assert nz.size <= c.shape[1]
+        assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp), _native.sparsemax_bwd(dyt, p, supp)):
+        assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
