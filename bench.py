@@ -453,6 +453,14 @@ def main():
             sweep_entry(f"K{K}_adversarial", K, R, chunks, lambda: adversarial(R, K))
         sweep_entry("K4096_sigma0.2", 4096, 1 << 20, 1, lambda: gen(1 << 20, 4096, 0.2, dev, 99))
         out["sweep"] = sweep
+        # the model-shaped calls (cfg1 [64,10], cfg2 [64,256], cfg4 top-k [64,10]):
+        # far too small for bandwidth, reported as launch latency of the fwd+bwd pair
+        small = {}
+        for R, K in ((64, 10), (64, 256)):
+            xs, dys = gen(R, K, 1.0, dev, 5)
+            w, fm, bm, _ = timed_sparsemax(native, xs, dys, 200, 20, 1, dev)
+            small[f"{R}x{K}"] = {"fwd_us": fm * 1e3, "bwd_us": bm * 1e3, "pair_wall_us": w / 200 * 1e6}
+        out["model_shaped_latency"] = small
         out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, 0.05)]
