@@ -97,19 +97,22 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
     L = native.lib()
     import ctypes
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mbytes = L.smlvm_sparsemax_support_mask_bytes(ctypes.c_int64(R), ctypes.c_int32(K))
+    mask = torch.empty(mbytes // 4, dtype=torch.int32, device=dev) if mbytes else None
+    mp = ctypes.c_void_p(mask.data_ptr()) if mask is not None else None
 
     # the pair lvmhelpers.functional.sparsemax runs: the forward also lists each row's support
     # columns (128 B per row) and the backward works from the lists (include/sparsemarg.h)
     def fwd():
         rc = L.smlvm_sparsemax_fwd_cols(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(p.data_ptr()),
                                         ctypes.c_void_p(supp.data_ptr()), None, None, None,
-                                        ctypes.c_void_p(cols.data_ptr()), ctypes.c_int32(cap),
+                                        ctypes.c_void_p(cols.data_ptr()), ctypes.c_int32(cap), mp,
                                         ctypes.c_int64(R), ctypes.c_int32(K), st)
         assert rc == 0, rc
 
     def bwd():
         rc = L.smlvm_sparsemax_bwd_cols(ctypes.c_void_p(dy.data_ptr()), ctypes.c_void_p(cols.data_ptr()),
-                                        ctypes.c_int32(cap), ctypes.c_void_p(p.data_ptr()),
+                                        ctypes.c_int32(cap), mp, ctypes.c_void_p(p.data_ptr()),
                                         ctypes.c_void_p(supp.data_ptr()), ctypes.c_void_p(dx.data_ptr()),
                                         ctypes.c_int64(R), ctypes.c_int32(K), st)
         assert rc == 0, rc

@@ -63,13 +63,20 @@ int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_siz
  *   threshold search could not run on a candidate list: more than 256 elements within 1 of the row
  *   maximum after the bound has been raised; for K > 4096 more than 64 of them in one wave's 64 E
  *   columns): the backward then reads p for that row exactly like smlvm_sparsemax_bwd.
- *   support_cols may be NULL (then these are the plain entry points). */
+ *   support_cols may be NULL (then these are the plain entry points).
+ *   support_mask (nullable; smlvm_sparsemax_support_mask_bytes(R, K) bytes, 0 unless
+ *   1024 < K <= 4096): for rows with more than cap non-zeros the forward leaves the non-zero
+ *   pattern there as a bitmap (layout private to the library) and marks the row -3 instead of -2;
+ *   the backward then gathers dy at those bits and still does not read p (rows with up to 96
+ *   non-zeros).  Pass the same buffer to both calls, or NULL to both. */
+size_t smlvm_sparsemax_support_mask_bytes(int64_t R, int32_t K);
 int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
-                             float* entropy, int32_t* support_cols, int32_t cap, int64_t R,
-                             int32_t K, void* stream);
+                             float* entropy, int32_t* support_cols, int32_t cap,
+                             uint32_t* support_mask, int64_t R, int32_t K, void* stream);
 int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32_t cap,
-                             const float* p, const int32_t* supp_size, float* dx, int64_t R,
-                             int32_t K, void* stream);
+                             const uint32_t* support_mask, const float* p,
+                             const int32_t* supp_size, float* dx, int64_t R, int32_t K,
+                             void* stream);
 
 /* Shannon entropy with exact zeros, lvmhelpers/marg.py:6-28 (also structmarg.py:9-20):
  * ent[r] = -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps), eps = FLT_EPSILON. */

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void support_count_kernel(const float* __restr
     if (row >= R) return;
     if (lists) {
         const int cl = lane < cap ? lists[row * cap + lane] : -1;
-        if (__builtin_amdgcn_readfirstlane(cl) != -2) {   // wave-uniform
+        if (__builtin_amdgcn_readfirstlane(cl) >= -1) {   // wave-uniform; -2 / -3: no list
             const int n = __popcll(__ballot(cl >= 0));
             if (lane == 0) nnz[row] = n;
             return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void support_compact_kernel(
     int64_t out = row_offsets[row];
     if (lists) {
         const int cl = lane < cap ? lists[row * cap + lane] : -1;
-        if (__builtin_amdgcn_readfirstlane(cl) != -2) {   // wave-uniform
+        if (__builtin_amdgcn_readfirstlane(cl) >= -1) {   // wave-uniform; -2 / -3: no list
             // the list is in no particular order: a lane's output slot is the rank of its column
             const int n = __popcll(__ballot(cl >= 0));
             int rank = 0;

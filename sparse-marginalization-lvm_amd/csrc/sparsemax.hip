@@ -348,7 +348,12 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
 // columns of p > 0 in no particular order, -1 in the unused slots; a first entry of -2 means "no
 // list for this row" (more than cap non-zeros, or a row wider than one wave's tile) and sends the
 // backward to the p-based path.
-constexpr int kColsNone = -1, kColsOverflow = -2, kColsMaxCap = 64;
+constexpr int kColsNone = -1, kColsOverflow = -2, kColsMask = -3, kColsMaxCap = 64;
+// kColsMask in slot 0: no list, but the row's non-zero pattern is in the support-mask buffer (one
+// 64-bit word per lane of the <64, E> tile, bit e = register e: a layout private to this file and
+// only written / read by the 16-byte-layout kernels with E >= 32, i.e. 1024 < K <= 4096).  The
+// backward then gathers dy at the set bits without reading p.
+constexpr int kMaskWordsPerRow = 128;   // 64 lanes x 2 x uint32
 
 template <int E, bool VEC>
 __device__ __forceinline__ int col_of(int e, int gl, int GT)
@@ -435,7 +440,8 @@ __device__ __forceinline__ float subset_bound(float v)
 template <int Q, int G>
 __device__ __forceinline__ void emit_cols_from_candidates(const float (&c)[Q], const int (&cc)[Q],
                                                           float tau, int gl, int grp,
-                                                          int32_t* __restrict__ list, int cap, bool live)
+                                                          int32_t* __restrict__ list, int cap, bool live,
+                                                          int mark = kColsOverflow)
 {
     int base = 0;
     bool wrote0 = false;
@@ -452,7 +458,7 @@ __device__ __forceinline__ void emit_cols_from_candidates(const float (&c)[Q], c
         }
     }
     if (live) {
-        if (base > cap) { if (wrote0) list[0] = kColsOverflow; }
+        if (base > cap) { if (wrote0) list[0] = mark; }
         else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
     }
 }
@@ -474,7 +480,7 @@ __device__ __forceinline__ void wave_lds_sync()
 template <int E, int NW, bool CAND, bool VEC, class Red>
 __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
                                               float& tau_out, int32_t* list = nullptr, int cap = 0,
-                                              bool live = true)
+                                              bool live = true, int mark = kColsOverflow)
 {
     float mx = z[0];
 #pragma unroll
@@ -620,7 +626,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
                 emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,
-                                                            live && (NW == 1 || threadIdx.x < 64));
+                                                            live && (NW == 1 || threadIdx.x < 64), mark);
             }
         }
     }
@@ -834,6 +840,11 @@ constexpr int kGatherMaxSupport = 96;   // ~ where 128-byte sectors per element 
 // in place (one register array; a 64-bit per-lane mask remembers where they are), zeros stay
 // zeros, so the fp64 row sum adds the same numbers in the same order as the streaming path.
 template <int E, bool VEC, class Red>
+__device__ __forceinline__ void bwd_row_gather_bits(const float* __restrict__ dyrow, int gl, int GT,
+                                                    float (&a)[E], uint32_t mlo, uint32_t mhi, int s,
+                                                    Red& red);
+
+template <int E, bool VEC, class Red>
 __device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, int gl, int GT,
                                                float (&a)[E], int s, Red& red)
 {
@@ -846,6 +857,15 @@ __device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, 
         t = t < 1u ? t : 1u;
         if (e < 32) mlo |= t << e; else mhi |= t << (e - 32);
     }
+    bwd_row_gather_bits<E, VEC>(dyrow, gl, GT, a, mlo, mhi, s, red);
+}
+
+// a[]: anything at the set bits (overwritten by the gathered dy), zero elsewhere on return
+template <int E, bool VEC, class Red>
+__device__ __forceinline__ void bwd_row_gather_bits(const float* __restrict__ dyrow, int gl, int GT,
+                                                    float (&a)[E], uint32_t mlo, uint32_t mhi, int s,
+                                                    Red& red)
+{
     asm volatile("" : "+v"(mlo), "+v"(mhi));
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -871,7 +891,8 @@ __device__ __forceinline__ void bwd_row_gather(const float* __restrict__ dyrow, 
 // slot 0 overwrites it with the overflow mark if the row has more than cap non-zeros.
 template <int E, int G, bool VEC>
 __device__ __forceinline__ void emit_support_cols(const float (&p)[E], int gl, int grp,
-                                                  int32_t* __restrict__ list, int cap, bool live)
+                                                  int32_t* __restrict__ list, int cap, bool live,
+                                                  int mark = kColsOverflow)
 {
     int base = 0;
     bool wrote0 = false;
@@ -888,7 +909,7 @@ __device__ __forceinline__ void emit_support_cols(const float (&p)[E], int gl, i
         }
     }
     if (live) {
-        if (base > cap) { if (wrote0) list[0] = kColsOverflow; }
+        if (base > cap) { if (wrote0) list[0] = mark; }
         else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
     }
 }
@@ -1014,11 +1035,13 @@ template <int G, int E, bool VEC, bool FULL, bool EXTRA>
 __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void sparsemax_fwd_wave_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
     int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
-    int32_t* __restrict__ cols, int cap, int64_t R, int K)
+    int32_t* __restrict__ cols, int cap, uint32_t* __restrict__ mask, int64_t R, int K)
 {
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
     int64_t row = wave_row<G>(lane);
+    constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
+    const int mark = (MASKS && mask != nullptr) ? kColsMask : kColsOverflow;
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
@@ -1037,9 +1060,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
                                                 list, cap, live);
     else
         listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
-                                                s, t, list, cap, live);
+                                                s, t, list, cap, live, mark);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
-    if (cols && !listed) emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live);
+    if (cols && !listed) emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark);
+    if constexpr (MASKS) {
+        // more than cap non-zeros (s is wave-uniform here): leave the pattern as one bit per register
+        if (cols && mask && s > cap && live) {
+            uint32_t mlo = 0u, mhi = 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t b = z[e] > 0.0f ? 1u : 0u;
+                if (e < 32) mlo |= b << e; else mhi |= b << (e - 32);
+            }
+            uint2* mrow = reinterpret_cast<uint2*>(mask + row * kMaskWordsPerRow);
+            mrow[lane] = make_uint2(mlo, mhi);
+        }
+    }
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
         if (gl == 0) {
@@ -1126,8 +1162,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
 template <int G, int E, bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void sparsemax_bwd_cols_wave_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ cols, int cap,
-    const float* __restrict__ p, const int32_t* __restrict__ supp, float* __restrict__ dx, int64_t R,
-    int K)
+    const uint32_t* __restrict__ mask, const float* __restrict__ p, const int32_t* __restrict__ supp,
+    float* __restrict__ dx, int64_t R, int K)
 {
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
@@ -1136,8 +1172,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     if (!live) row = R - 1;
     const int s = supp[row];
     const int32_t* list = cols + row * cap;
+    const int head = list[0];
     WaveRed<G> red;
-    if (__ballot(list[0] == kColsOverflow) == 0ull) {   // every row of this wave has its list
+    constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
+    if constexpr (MASKS) {
+        // no list, but the forward left the non-zero pattern (head and s are wave-uniform here)
+        if (mask && head == kColsMask && s <= kGatherMaxSupport) {
+            const uint2 m = reinterpret_cast<const uint2*>(mask + row * kMaskWordsPerRow)[lane];
+            float a[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = 0.0f;
+            bwd_row_gather_bits<E, VEC>(dy + row * K, gl, G, a, m.x, m.y, s, red);
+            if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+            return;
+        }
+    }
+    if (__ballot(head < kColsNone) == 0ull) {   // every row of this wave has its list
         if constexpr (E <= 16) {
             float a[E];
             bwd_tile_from_cols<E, G, VEC>(dy + row * K, list, cap, gl, lane, s, red, a);
@@ -1254,12 +1304,14 @@ struct FwdArgs {
     int64_t R; int K; hipStream_t st;
     bool vec, extra;
     int32_t* cols; int cap;
+    uint32_t* mask;
 };
 struct BwdArgs {
     const float* dy; const float* p; const int32_t* supp; float* dx;
     int64_t R; int K; hipStream_t st;
     bool vec;
     const int32_t* cols; int cap;
+    const uint32_t* mask;
 };
 
 static unsigned wave_grid(int64_t R, int G)
@@ -1274,7 +1326,7 @@ static void fwd_wave_go(const FwdArgs& a)
 {
     hipLaunchKernelGGL((sparsemax_fwd_wave_kernel<G, E, VEC, FULL, EXTRA>), dim3(wave_grid(a.R, G)),
                        dim3(64 * kWavesPerBlock), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent,
-                       a.cols, a.cap, a.R, a.K);
+                       a.cols, a.cap, a.mask, a.R, a.K);
 }
 template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
 static void fwd_block_go(const FwdArgs& a)
@@ -1288,8 +1340,8 @@ static void bwd_wave_go(const BwdArgs& a)
 {
     if (a.cols)
         hipLaunchKernelGGL((sparsemax_bwd_cols_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
-                           dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.cols, a.cap, a.p, a.supp, a.dx,
-                           a.R, a.K);
+                           dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.cols, a.cap, a.mask, a.p, a.supp,
+                           a.dx, a.R, a.K);
     else
         hipLaunchKernelGGL((sparsemax_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
                            dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
@@ -1378,14 +1430,21 @@ extern "C" int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size,
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
-              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, nullptr, 0};
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, nullptr, 0, nullptr};
     SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
 
+extern "C" size_t smlvm_sparsemax_support_mask_bytes(int64_t R, int32_t K)
+{
+    if (R <= 0 || K <= 1024 || K > 4096) return 0;
+    return (size_t)R * kMaskWordsPerRow * sizeof(uint32_t);
+}
+
 extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz,
                                         float* tau, float* entropy, int32_t* support_cols,
-                                        int32_t cap, int64_t R, int32_t K, void* stream)
+                                        int32_t cap, uint32_t* support_mask, int64_t R, int32_t K,
+                                        void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
     if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
@@ -1393,7 +1452,8 @@ extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
-              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap};
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap,
+              (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
     SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
@@ -1406,14 +1466,15 @@ extern "C" int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
-              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx), nullptr, 0};
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx), nullptr, 0, nullptr};
     SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }
 
 extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32_t cap,
-                                        const float* p, const int32_t* supp_size, float* dx,
-                                        int64_t R, int32_t K, void* stream)
+                                        const uint32_t* support_mask, const float* p,
+                                        const int32_t* supp_size, float* dx, int64_t R, int32_t K,
+                                        void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
     if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
@@ -1422,7 +1483,7 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
     if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
-              support_cols, cap};
+              support_cols, cap, (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
     SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
-    "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
+    "smlvm_sparsemax_support_mask_bytes", "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
     "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
@@ -46,6 +46,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.smlvm_error_string.restype = ctypes.c_char_p
         L.smlvm_support_offsets_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_sparsemax_support_mask_bytes.restype = ctypes.c_size_t
+        L.smlvm_sparsemax_support_mask_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
         L.smlvm_weighted_loss_reduce_workspace_bytes.restype = ctypes.c_size_t
         L.smlvm_weighted_loss_reduce_workspace_bytes.argtypes = [ctypes.c_int64]
@@ -92,9 +94,13 @@ _f32 = ctypes.c_float
 SUPPORT_COLS_CAP = 32   # slots per row of the forward's support list (128 B per row)
 
 
-def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False):
+def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False,
+                  want_mask=False):
     """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None).
-    want_cols=True appends the support lists [R, SUPPORT_COLS_CAP] i32 for sparsemax_bwd_cols."""
+    want_cols=True appends the support lists [R, SUPPORT_COLS_CAP] i32 for sparsemax_bwd_cols;
+    want_mask=True (with want_cols) appends the support-mask buffer as well (None when the shape
+    has none: only 1024 < K <= 4096), which lets the backward skip p for rows with more non-zeros
+    than a list holds."""
     x = _need_gpu(x, torch.float32, "x")
     R, K = x.shape
     p = torch.empty_like(x)
@@ -108,23 +114,35 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
                                              _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
         return p, supp, nnz, tau, ent
     cols = torch.empty((R, SUPPORT_COLS_CAP), dtype=torch.int32, device=x.device)
+    mask = None
+    if want_mask:
+        nbytes = lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K))
+        if nbytes:
+            mask = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
-                                              _p(cols), _i32(SUPPORT_COLS_CAP), _i64(R), _i32(K),
-                                              _stream()), "smlvm_sparsemax_fwd_cols")
+                                              _p(cols), _i32(SUPPORT_COLS_CAP), _p(mask), _i64(R),
+                                              _i32(K), _stream()), "smlvm_sparsemax_fwd_cols")
+    if want_mask:
+        return p, supp, nnz, tau, ent, cols, mask
     return p, supp, nnz, tau, ent, cols
 
 
-def sparsemax_bwd_cols(dy, cols, p, supp):
-    """Backward from the forward's support lists (p is only read for rows without a list)."""
+def sparsemax_bwd_cols(dy, cols, p, supp, mask=None):
+    """Backward from the forward's support lists (p is only read for rows that have neither a list
+    nor, with `mask` from the same forward, a support mask)."""
     dy = _need_gpu(dy, torch.float32, "dy")
     p = _need_gpu(p, torch.float32, "p")
     cols = _need_gpu(cols, torch.int32, "cols")
     R, K = p.shape
+    if mask is not None:
+        mask = _need_gpu(mask, torch.int32, "mask")
+        if mask.numel() * 4 < lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K)):
+            raise ValueError("support mask too small for this shape")
     dx = torch.empty_like(p)
     with torch.cuda.device(p.device):
-        _check(lib().smlvm_sparsemax_bwd_cols(_p(dy), _p(cols), _i32(cols.shape[1]), _p(p), _p(supp),
-                                              _p(dx), _i64(R), _i32(K), _stream()),
+        _check(lib().smlvm_sparsemax_bwd_cols(_p(dy), _p(cols), _i32(cols.shape[1]), _p(mask), _p(p),
+                                              _p(supp), _p(dx), _i64(R), _i32(K), _stream()),
                "smlvm_sparsemax_bwd_cols")
     return dx
 

@@ -10,15 +10,18 @@ class _Sparsemax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         shape = x.shape
-        p, supp, _, _, _, cols = _native.sparsemax_fwd(x.reshape(-1, shape[-1]), want_cols=True)
-        ctx.save_for_backward(p, supp, cols)
+        p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(x.reshape(-1, shape[-1]), want_cols=True,
+                                                             want_mask=True)
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(p, supp, cols, *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(cols)
         return p.view(shape), cols
 
     @staticmethod
     def backward(ctx, dy, _dcols=None):
-        p, supp, cols = ctx.saved_tensors
-        dx = _native.sparsemax_bwd_cols(dy.reshape(p.shape).contiguous(), cols, p, supp)
+        p, supp, cols = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
+        dx = _native.sparsemax_bwd_cols(dy.reshape(p.shape).contiguous(), cols, p, supp, mask)
         return dx.view(dy.shape)
 
 
@@ -27,14 +30,17 @@ class _SparsemaxEntropy(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        p, supp, _, _, ent, cols = _native.sparsemax_fwd(x, want_entropy=True, want_cols=True)
-        ctx.save_for_backward(p, supp, cols)
+        p, supp, _, _, ent, cols, mask = _native.sparsemax_fwd(x, want_entropy=True, want_cols=True,
+                                                               want_mask=True)
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(p, supp, cols, *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(supp, cols)
         return p, ent, supp, cols
 
     @staticmethod
     def backward(ctx, dp, dent, _dsupp, _dcols=None):
-        p, supp, cols = ctx.saved_tensors
+        p, supp, cols = ctx.saved_tensors[:3]
+        mask = ctx.saved_tensors[3] if ctx.has_mask else None
         if dp is None and dent is None:
             return torch.zeros_like(p)
         if dent is None:
@@ -43,7 +49,7 @@ class _SparsemaxEntropy(torch.autograd.Function):
             g = _entropy_vjp(p, dent)
         else:
             g = dp + _entropy_vjp(p, dent)
-        return _native.sparsemax_bwd_cols(g.contiguous(), cols, p, supp)
+        return _native.sparsemax_bwd_cols(g.contiguous(), cols, p, supp, mask)
 
 
 def _entropy_vjp(p, dent):

@@ -71,6 +71,16 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(0), null) == 0
     assert lib.smlvm_segmented_logsumexp(null, null, ctypes.c_float(0.0), null, i64(3), null) == -1
     assert lib.smlvm_support_compact(null, null, null, null, null, i64(3), i32(4), null) == -1
+    assert lib.smlvm_sparsemax_fwd_cols(one, one, one, null, null, null, one, i32(0), null, i64(3), i32(4), null) == -1   # cap
+    assert lib.smlvm_sparsemax_fwd_cols(one, one, one, null, null, null, one, i32(65), null, i64(3), i32(4), null) == -1
+    assert lib.smlvm_sparsemax_fwd_cols(null, null, null, null, null, null, null, i32(0), null, i64(0), i32(4), null) == 0
+    assert lib.smlvm_sparsemax_bwd_cols(one, one, i32(0), null, one, one, one, i64(3), i32(4), null) == -1
+    assert lib.smlvm_sparsemax_bwd_cols(one, one, i32(8), null, one, one, null, i64(3), i32(4), null) == -1   # dx
+    lib.smlvm_sparsemax_support_mask_bytes.restype = ctypes.c_size_t
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(4096)) == 10 * 512
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(1025)) == 10 * 512
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(1024)) == 0
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(4100)) == 0
     assert lib.smlvm_support_compact_cols(null, null, i32(0), null, null, null, null, i64(0), i32(4), null) == 0
     assert lib.smlvm_support_compact_cols(one, one, i32(65), one, null, null, null, i64(3), i32(4), null) == -1
     assert lib.smlvm_support_count_cols(one, one, i32(0), one, i64(3), i32(4), null) == -1

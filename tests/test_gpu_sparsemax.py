@@ -198,7 +198,7 @@ def test_support_lists_and_list_backward(dev, oracle_mod, R, K, kind):
     for r in range(R):
         nz = np.flatnonzero(p_ref[r] > 0)
         if nz.size > cap:
-            assert c[r, 0] == -2
+            assert c[r, 0] in (-2, -3)
         elif K > 4096 and c[r, 0] == -2:
             # rows held by several waves list their support only when the threshold search ran on
             # the candidate list (<= 64 elements within 1 of the maximum per wave, <= 256 per row)
@@ -261,7 +261,7 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     for r in range(R):
         nz = np.flatnonzero(p_ref[r] > 0)
         if nz.size > cap:
-            assert c[r, 0] == -2
+            assert c[r, 0] in (-2, -3)
         elif K <= 4096 or c[r, 0] != -2:   # wide rows may keep no list (per-wave candidate limit)
             assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
     dx = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp).cpu().numpy()
@@ -300,3 +300,41 @@ def test_list_pair_on_rows_that_are_not_16_byte_addressable(dev, oracle_mod, R, 
     scale = np.abs(dy).max(axis=1, keepdims=True)
     for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp), _native.sparsemax_bwd(dyt, p, supp)):
         assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+
+
+@pytest.mark.parametrize("K,sigma", [(4096, 0.05), (4096, 0.02), (3000, 0.05), (2048, 0.03), (1028, 0.05),
+                                     (4096, 0.005), (4096, 1.0)])
+def test_support_mask_backward(dev, oracle_mod, K, sigma):
+    """Rows with more non-zeros than a list holds: with the support-mask buffer the forward marks
+    them -3 and leaves their non-zero pattern, and the backward gathers dy at those bits instead of
+    reading p.  Same numbers in the same order as the p-based gather: dx must be bit-identical to
+    it, and within 1e-6 of the oracle; without the buffer the mark stays -2."""
+    from lvmhelpers import _native
+    R = 300
+    rng = np.random.default_rng(K + int(1e4 * sigma))
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    x[::7] *= 20                      # some rows with a short support: they keep their lists
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    xt, dyt = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
+    assert mask is not None and np.array_equal(p.cpu().numpy(), p_ref)
+    head = cols[:, 0].cpu().numpy()
+    nnz = (p_ref > 0).sum(1)
+    cap = cols.shape[1]
+    assert np.all(head[nnz > cap] == -3) and np.all(head[nnz <= cap] >= 0)
+    dx_mask = _native.sparsemax_bwd_cols(dyt, cols, p, supp, mask)
+    dx_p = _native.sparsemax_bwd(dyt, p, supp)
+    assert torch.equal(dx_mask, dx_p)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    assert np.all(np.abs(dx_mask.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+    # p is not read for the masked rows: poison it where the mask applies (<= 96 non-zeros)
+    poisoned = p.clone()
+    poisoned[torch.from_numpy((nnz > cap) & (s_ref <= 96)).to(dev)] = float("nan")
+    assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols, poisoned, supp, mask), dx_mask)
+    # without the buffer: plain overflow marks, p-based backward
+    _, _, _, _, _, cols2 = _native.sparsemax_fwd(xt, want_cols=True)
+    h2 = cols2[:, 0].cpu().numpy()
+    assert np.all(h2[nnz > cap] == -2)
+    assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols2, p, supp), dx_p)

@@ -23,8 +23,8 @@ __global__ void k_gauss(float* x, size_t n, float sigma, unsigned long long seed
     }
 }
 
-typedef int (*fwd_cols_t)(const float*, float*, int32_t*, int32_t*, float*, float*, int32_t*, int, int64_t, int, void*);
-typedef int (*bwd_cols_t)(const float*, const int32_t*, int, const float*, const int32_t*, float*, int64_t, int, void*);
+typedef int (*fwd_cols_t)(const float*, float*, int32_t*, int32_t*, float*, float*, int32_t*, int, uint32_t*, int64_t, int, void*);
+typedef int (*bwd_cols_t)(const float*, const int32_t*, int, const uint32_t*, const float*, const int32_t*, float*, int64_t, int, void*);
 typedef int (*fwd_t)(const float*, float*, int32_t*, int32_t*, float*, float*, int64_t, int, void*);
 typedef int (*bwd_t)(const float*, const float*, const int32_t*, float*, int64_t, int, void*);
 
@@ -47,6 +47,8 @@ int main(int argc, char** argv)
     float *x, *p, *dy, *dx; int32_t *supp, *cols;
     CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4));
     CK(hipMalloc(&supp, R * 4)); CK(hipMalloc(&cols, (size_t)R * cap * 4));
+    uint32_t* mask = nullptr;
+    if (K > 1024 && K <= 4096 && !getenv("SMX_NO_MASK")) CK(hipMalloc(&mask, (size_t)R * 512));
     hipLaunchKernelGGL(k_gauss, dim3(4096), dim3(256), 0, 0, x, n, sigma, 1ull);
     hipLaunchKernelGGL(k_gauss, dim3(4096), dim3(256), 0, 0, dy, n, 1.0f, 77ull);
     CK(hipDeviceSynchronize());
@@ -62,8 +64,8 @@ int main(int argc, char** argv)
     time_it("fwd", [&] { return fwd(x, p, supp, nullptr, nullptr, nullptr, R, K, nullptr); });
     time_it("bwd", [&] { return bwd(dy, p, supp, dx, R, K, nullptr); });
     if (fwdc && bwdc) {
-        time_it("fwd_cols", [&] { return fwdc(x, p, supp, nullptr, nullptr, nullptr, cols, cap, R, K, nullptr); });
-        time_it("bwd_cols", [&] { return bwdc(dy, cols, cap, p, supp, dx, R, K, nullptr); });
+        time_it("fwd_cols", [&] { return fwdc(x, p, supp, nullptr, nullptr, nullptr, cols, cap, mask, R, K, nullptr); });
+        time_it("bwd_cols", [&] { return bwdc(dy, cols, cap, mask, p, supp, dx, R, K, nullptr); });
     }
     return 0;
 }
