@@ -1298,6 +1298,337 @@ __global__ __launch_bounds__(256) void entropy_kernel(const float* __restrict__ 
     if (lane == 0) ent[row] = -(float)acc;
 }
 
+// ------------------------------------------------------------------------------- K > 65536
+// Rows wider than one workgroup's registers (65536 elements) stay in memory: one 1024-thread block
+// per row streams it -- max; the subset bound from the lane maxima; the candidates above it into
+// per-wave LDS lists (the same <= 64 per wave, <= 256 per row as the block kernel), re-tried above
+// a bound raised by streaming Michelot steps when they do not fit; the threshold search on the
+// candidates in registers; p -- so a row is read three times (twice out of the L2 / Infinity Cache)
+// and written once.  Rows whose support does not fit a candidate list run the whole search,
+// edge passes included, as streaming passes.  Results are the same bits as the register kernels'.
+constexpr int kStreamNW = 16;
+
+template <bool VEC>
+struct RowStream {
+    const float* row;
+    int K;
+    float mx;
+    // f(value in the shifted frame); every element once, in a fixed per-thread order
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) const
+    {
+        if constexpr (VEC) {
+            const float4* r4 = reinterpret_cast<const float4*>(row);
+            const int K4 = K >> 2;
+            for (int i = threadIdx.x; i < K4; i += 64 * kStreamNW) {
+                const float4 v = r4[i];
+                f(v.x - mx); f(v.y - mx); f(v.z - mx); f(v.w - mx);
+            }
+        } else {
+            for (int c = threadIdx.x; c < K; c += 64 * kStreamNW) f(row[c] - mx);
+        }
+    }
+};
+
+// solve_core with the row behind a RowStream (same decisions, every pass re-reads the row)
+template <class Src, class Red>
+__device__ void solve_stream(const Src& src, Red& red, float tau, int& s_out, double& S_out)
+{
+    int cnt_prev = 0x7fffffff;
+    for (;;) {
+        int c = 0;
+        float sm = 0.0f;
+        src.each([&](float v) { const bool in = v > tau; c += in ? 1 : 0; sm += in ? v : 0.0f; });
+        red.cs(c, sm);
+        if (c >= cnt_prev) break;
+        cnt_prev = c;
+        tau = fmaxf(tau, (sm - 1.0f) / (float)c);
+    }
+    float lo = INFINITY;
+    src.each([&](float v) { lo = (v > tau) ? fminf(lo, v) : lo; });
+    lo = red.min(lo);
+    int s_final;
+    double S_final;
+    int dir = 0;
+    bool probe = false;
+    for (;;) {
+        Edge b;
+        {
+            int mg = 0, t = 0;
+            double S = 0.0;
+            float vn = -INFINITY;
+            src.each([&](float v) {
+                const bool gt = v > lo;
+                mg += gt ? 1 : 0;
+                t += (v == lo) ? 1 : 0;
+                S += gt ? (double)v : 0.0;
+                vn = (v < lo) ? fmaxf(vn, v) : vn;
+            });
+            red.edge(mg, t, S, vn);
+            b.m_gt = mg; b.t = t; b.S_gt = S; b.vnext = vn;
+        }
+        if (probe) {
+            int cnt = 0;
+            if (b.t > 1 && b.t <= kTieExact) cnt = count_ranks(b.m_gt, b.S_gt, lo, b.t);
+            s_final = b.m_gt + cnt;
+            S_final = b.S_gt + (double)cnt * (double)lo;
+            break;
+        }
+        int rstar;
+        if (b.t > 1 && b.t <= kTieExact) {
+            rstar = count_ranks(b.m_gt, b.S_gt, lo, b.t);
+        } else if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
+            rstar = b.t;
+        } else if (b.t == 1 || !cond_rank(b.m_gt, b.S_gt, lo, 1)) {
+            rstar = 0;
+        } else {
+            int a = 1, hi = b.t;
+            while (hi - a > 1) {
+                int mid = (a + hi) >> 1;
+                if (cond_rank(b.m_gt, b.S_gt, lo, mid)) a = mid; else hi = mid;
+            }
+            rstar = a;
+        }
+        if (rstar == b.t) {
+            int m = b.m_gt + b.t;
+            double S_m = b.S_gt + (double)b.t * (double)lo;
+            if (dir >= 0 && b.vnext > -INFINITY) {
+                if (cond_rank(m, S_m, b.vnext, 1)) { dir = 1; lo = b.vnext; continue; }
+                if (near_rank(m, S_m, b.vnext)) { probe = true; lo = b.vnext; continue; }
+            }
+            s_final = m;
+            S_final = S_m;
+            break;
+        }
+        if (rstar > 0 || dir > 0 || b.m_gt == 0) {
+            s_final = b.m_gt + rstar;
+            S_final = b.S_gt + (double)rstar * (double)lo;
+            if (s_final == 0) { s_final = b.t; S_final = (double)b.t * (double)lo; }
+            break;
+        }
+        dir = -1;
+        float up = INFINITY;
+        src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
+        lo = red.min(up);
+    }
+    s_out = s_final;
+    S_out = S_final;
+}
+
+template <bool VEC, bool EXTRA>
+__global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
+    const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
+    int32_t* __restrict__ nnz, float* __restrict__ tau_o, float* __restrict__ ent,
+    int32_t* __restrict__ cols, int cap, int64_t R, int K)
+{
+    constexpr int NW = kStreamNW, NT = 64 * NW;
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    __shared__ float cand[2 * NW * 64 + NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* cnt = reinterpret_cast<int*>(cand + NW * 64);
+    int* ccols = cnt + NW;
+    const int nstep = VEC ? (K >> 2) : K;   // float4 chunks or elements per row
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        const float* xr = x + row * K;
+        BlockRed<NW> red(lds);
+        float lm = -INFINITY;
+        {
+            RowStream<VEC> raw{xr, K, 0.0f};
+            raw.each([&](float v) { lm = fmaxf(lm, v); });
+        }
+        const float mx = red.max(lm);
+        const float lane_mx = lm - mx;
+        const RowStream<VEC> src{xr, K, mx};
+        // lower bound of tau from the lane maxima: wave-local, then over all 1024 of them
+        float tau = red.max(subset_bound(lane_mx));
+        for (int cp = 0x7fffffff;;) {
+            const bool in = lane_mx > tau;
+            int cn = in ? 1 : 0;
+            float sm = in ? lane_mx : 0.0f;
+            red.cs(cn, sm);
+            if (cn >= cp) break;
+            cp = cn;
+            tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+        }
+        float thr = fmaxf(tau - kLazyMargin, -1.0f);
+        float c[kCandPerLane];
+        int cc[kCandPerLane];
+        bool fast = false;
+        int cnt_prev = 0x7fffffff, passes = 0;
+        for (;;) {
+            int base = 0;
+            for (int i0 = 0; i0 < nstep; i0 += NT) {   // block-uniform trip count
+                const int i = i0 + threadIdx.x;
+                const bool ok = i < nstep;
+                float v[VEC ? 4 : 1];
+                if constexpr (VEC) {
+                    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) q = reinterpret_cast<const float4*>(xr)[i];
+                    v[0] = q.x - mx; v[1] = q.y - mx; v[2] = q.z - mx; v[3] = q.w - mx;
+                } else {
+                    v[0] = (ok ? xr[i] : 0.0f) - mx;
+                }
+#pragma unroll
+                for (int j = 0; j < (VEC ? 4 : 1); ++j) {
+                    const bool in = ok && v[j] > thr;
+                    const unsigned long long m = __ballot(in);
+                    if (m != 0ull && base <= 64) {
+                        const int off = base + lanes_below(m);
+                        if (in && off < 64) {
+                            cand[wave * 64 + off] = v[j];
+                            ccols[wave * 64 + off] = VEC ? 4 * i + j : i;
+                        }
+                        base += __popcll(m);
+                    }
+                }
+            }
+            if (lane == 0) cnt[wave] = base;
+            __syncthreads();
+            int total = 0, worst = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const int k = cnt[w];
+                total += k;
+                worst = k > worst ? k : worst;
+            }
+            fast = worst <= 64 && total <= kCandCap;
+            if (fast) {
+#pragma unroll
+                for (int q = 0; q < kCandPerLane; ++q) {
+                    const int idx = lane + 64 * q;
+                    float vv = -INFINITY;
+                    int vc = 0, pre = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int k = cnt[w];
+                        if (idx >= pre && idx < pre + k) {
+                            vv = cand[w * 64 + (idx - pre)];
+                            vc = ccols[w * 64 + (idx - pre)];
+                        }
+                        pre += k;
+                    }
+                    c[q] = vv;
+                    cc[q] = vc;
+                }
+            }
+            __syncthreads();
+            if (fast) break;
+            bool give_up = false;
+            for (;;) {
+                int cn = 0;
+                float sm = 0.0f;
+                src.each([&](float v) { const bool in = v > tau; cn += in ? 1 : 0; sm += in ? v : 0.0f; });
+                red.cs(cn, sm);
+                if (cn >= cnt_prev || ++passes > kLazyPasses) { give_up = true; break; }
+                cnt_prev = cn;
+                tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+                if (cn <= kLazyTry) break;
+            }
+            if (give_up) break;
+            thr = tau - kLazyMargin;
+        }
+        int s_final = 1;
+        double S_final = 0.0;
+        int32_t* list = cols ? cols + row * cap : nullptr;
+        if (fast) {
+            WaveRed<64> wred;
+            solve_core(c, wred, s_final, S_final);
+            if (list) {
+                const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+                emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,
+                                                            threadIdx.x < 64);
+            }
+        } else {
+            solve_stream(src, red, tau, s_final, S_final);
+            if (list && threadIdx.x == 0) list[0] = kColsOverflow;
+        }
+        const float tau_f = ((float)S_final - 1.0f) / (float)s_final;
+        int n = 0;
+        double h = 0.0;
+        auto out1 = [&](float xv) {
+            const float pv = fmaxf((xv - mx) - tau_f, 0.0f);
+            if constexpr (EXTRA) {
+                n += pv > 0.0f ? 1 : 0;
+                if (ent && pv > 0.0f) {
+                    const float pc = fminf(fmaxf(pv, FLT_EPSILON), 1.0f - FLT_EPSILON);
+                    h += (double)(pc * logf(pc));
+                }
+            }
+            return pv;
+        };
+        float* pr = p + row * K;
+        if constexpr (VEC) {
+            const float4* r4 = reinterpret_cast<const float4*>(xr);
+            float4* o4 = reinterpret_cast<float4*>(pr);
+            for (int i = threadIdx.x; i < nstep; i += NT) {
+                const float4 q = nt_load4(r4 + i);
+                nt_store4(o4 + i, make_float4(out1(q.x), out1(q.y), out1(q.z), out1(q.w)));
+            }
+        } else {
+            for (int i = threadIdx.x; i < K; i += NT) pr[i] = out1(xr[i]);
+        }
+        if constexpr (EXTRA) {
+            if (nnz) n = red.sum(n);
+            if (ent) h = red.sum(h);
+        }
+        if (threadIdx.x == 0) {
+            supp[row] = s_final;
+            if constexpr (EXTRA) {
+                if (nnz) nnz[row] = n;
+                if (tau_o) tau_o[row] = tau_f;
+                if (ent) ent[row] = -(float)h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// p-based backward of such rows (rows that have a support list are written by the segment kernel)
+template <bool VEC>
+__global__ __launch_bounds__(64 * kStreamNW) void sparsemax_bwd_stream_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ supp,
+    float* __restrict__ dx, int64_t R, int K, const int32_t* __restrict__ cols, int cap)
+{
+    constexpr int NW = kStreamNW, NT = 64 * NW;
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        if (cols && cols[row * cap] >= kColsNone) continue;   // block-uniform
+        BlockRed<NW> red(lds);
+        const float* pr = p + row * K;
+        const float* gr = dy + row * K;
+        float* o = dx + row * K;
+        double acc = 0.0;
+        if constexpr (VEC) {
+            const float4* p4 = reinterpret_cast<const float4*>(pr);
+            const float4* g4 = reinterpret_cast<const float4*>(gr);
+            for (int i = threadIdx.x; i < (K >> 2); i += NT) {
+                const float4 a = p4[i], g = g4[i];
+                acc += a.x != 0.0f ? (double)g.x : 0.0;
+                acc += a.y != 0.0f ? (double)g.y : 0.0;
+                acc += a.z != 0.0f ? (double)g.z : 0.0;
+                acc += a.w != 0.0f ? (double)g.w : 0.0;
+            }
+        } else {
+            for (int i = threadIdx.x; i < K; i += NT) acc += pr[i] != 0.0f ? (double)gr[i] : 0.0;
+        }
+        acc = red.sum(acc);
+        const float v = (float)acc / (float)supp[row];
+        if constexpr (VEC) {
+            const float4* p4 = reinterpret_cast<const float4*>(pr);
+            const float4* g4 = reinterpret_cast<const float4*>(gr);
+            float4* o4 = reinterpret_cast<float4*>(o);
+            for (int i = threadIdx.x; i < (K >> 2); i += NT) {
+                const float4 a = p4[i], g = g4[i];
+                nt_store4(o4 + i, make_float4(a.x != 0.0f ? g.x - v : 0.0f, a.y != 0.0f ? g.y - v : 0.0f,
+                                              a.z != 0.0f ? g.z - v : 0.0f, a.w != 0.0f ? g.w - v : 0.0f));
+            }
+        } else {
+            for (int i = threadIdx.x; i < K; i += NT) o[i] = pr[i] != 0.0f ? gr[i] - v : 0.0f;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------- dispatch
 struct FwdArgs {
     const float* x; float* p; int32_t* supp; int32_t* nnz; float* tau; float* ent;
@@ -1346,23 +1677,11 @@ static void bwd_wave_go(const BwdArgs& a)
         hipLaunchKernelGGL((sparsemax_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
                            dim3(64 * kWavesPerBlock), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K);
 }
+static void launch_cols_segments(const BwdArgs& a);
 template <int NW, int E, bool VEC, bool FULL>
 static void bwd_block_go(const BwdArgs& a)
 {
-    if (a.cols) {   // listed rows first, one wave per 4096-column segment
-        const int nseg = (a.K + 4095) / 4096;
-        const int64_t waves = a.R * nseg;
-        const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
-        if (!a.vec)
-            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<false, false>), grid, dim3(64 * kWavesPerBlock),
-                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
-        else if (a.K % 4096 == 0)
-            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, true>), grid, dim3(64 * kWavesPerBlock),
-                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
-        else
-            hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, false>), grid, dim3(64 * kWavesPerBlock),
-                               0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
-    }
+    if (a.cols) launch_cols_segments(a);   // listed rows first, one wave per 4096-column segment
     hipLaunchKernelGGL((sparsemax_bwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)),
                        dim3(64 * NW), 0, a.st, a.dy, a.p, a.supp, a.dx, a.R, a.K, a.cols, a.cap);
 }
@@ -1401,6 +1720,45 @@ static void launch_bwd_block(const BwdArgs& a)
     else           bwd_block_go<A, E, true, false>(a);
 }
 
+static void launch_fwd_stream(const FwdArgs& a)
+{
+    const dim3 grid(block_grid(a.R)), block(64 * kStreamNW);
+#define SMLVM_FWD_STREAM(V, X)                                                                  \
+    hipLaunchKernelGGL((sparsemax_fwd_stream_kernel<V, X>), grid, block, 0, a.st, a.x, a.p, a.supp, \
+                       a.nnz, a.tau, a.ent, a.cols, a.cap, a.R, a.K)
+    if (a.vec) { if (a.extra) SMLVM_FWD_STREAM(true, true); else SMLVM_FWD_STREAM(true, false); }
+    else       { if (a.extra) SMLVM_FWD_STREAM(false, true); else SMLVM_FWD_STREAM(false, false); }
+#undef SMLVM_FWD_STREAM
+}
+
+static void launch_cols_segments(const BwdArgs& a)
+{
+    const int nseg = (a.K + 4095) / 4096;
+    const int64_t waves = a.R * nseg;
+    const dim3 grid((unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock));
+    if (!a.vec)
+        hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<false, false>), grid, dim3(64 * kWavesPerBlock),
+                           0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+    else if (a.K % 4096 == 0)
+        hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, true>), grid, dim3(64 * kWavesPerBlock),
+                           0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+    else
+        hipLaunchKernelGGL((sparsemax_bwd_cols_segment_kernel<true, false>), grid, dim3(64 * kWavesPerBlock),
+                           0, a.st, a.dy, a.cols, a.cap, a.supp, a.dx, a.R, a.K, nseg);
+}
+
+static void launch_bwd_stream(const BwdArgs& a)
+{
+    if (a.cols) launch_cols_segments(a);
+    const dim3 grid(block_grid(a.R)), block(64 * kStreamNW);
+    if (a.vec)
+        hipLaunchKernelGGL((sparsemax_bwd_stream_kernel<true>), grid, block, 0, a.st, a.dy, a.p, a.supp,
+                           a.dx, a.R, a.K, a.cols, a.cap);
+    else
+        hipLaunchKernelGGL((sparsemax_bwd_stream_kernel<false>), grid, block, 0, a.st, a.dy, a.p, a.supp,
+                           a.dx, a.R, a.K, a.cols, a.cap);
+}
+
 // Shape table: smallest register tile whose capacity covers K.
 #define SMLVM_DISPATCH(WAVE, BLOCK, args)                                                       \
     do {                                                                                        \
@@ -1428,10 +1786,10 @@ extern "C" int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size,
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
-    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, nullptr, 0, nullptr};
-    SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
+    if (K > 65536) launch_fwd_stream(a);
+    else SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
 
@@ -1450,11 +1808,11 @@ extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_
     if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
-    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap,
               (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
-    SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
+    if (K > 65536) launch_fwd_stream(a);
+    else SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
 
@@ -1464,10 +1822,10 @@ extern "C" int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
-    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx), nullptr, 0, nullptr};
-    SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
+    if (K > 65536) launch_bwd_stream(a);
+    else SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }
 
@@ -1480,11 +1838,11 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
     if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
-    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
               support_cols, cap, (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
-    SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
+    if (K > 65536) launch_bwd_stream(a);
+    else SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();
 }
 

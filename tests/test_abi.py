@@ -51,7 +51,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_sparsemax_bwd(null, null, null, null, i64(0), i32(8), null) == 0
     assert lib.smlvm_sparsemax_bwd(null, null, null, null, i64(2), i32(8), null) == -1
     one = ctypes.c_void_p(16)
-    assert lib.smlvm_sparsemax_fwd(one, one, one, null, null, null, i64(4), i32(70000), null) == -2    # K too large
+    assert lib.smlvm_sparsemax_fwd(null, one, one, null, null, null, i64(4), i32(70000), null) == -1   # any K is served; NULL x is not
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(3), i32(9), null) == -1           # k > 2^n
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(8), i32(1), null) == -1           # k < 2
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(600), i32(4), null) == -2

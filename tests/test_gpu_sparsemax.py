@@ -338,3 +338,44 @@ def test_support_mask_backward(dev, oracle_mod, K, sigma):
     h2 = cols2[:, 0].cpu().numpy()
     assert np.all(h2[nnz > cap] == -2)
     assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols2, p, supp), dx_p)
+
+
+@pytest.mark.parametrize("kind", ["normal", "narrow", "verynarrow", "adversarial"])
+@pytest.mark.parametrize("R,K", [(3, 65540), (2, 100000), (2, 131072), (2, 200001), (1, 262144)])
+def test_rows_wider_than_a_workgroup(dev, oracle_mod, R, K, kind):
+    """K > 65536: the row does not fit one workgroup's registers and is streamed (three reads out of
+    HBM / cache, one write).  Same bar as everywhere: p, supp, tau bit-exact, lists exact, dx within
+    1e-6 of the row scale, for both backward entry points."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(K + R)
+    if kind == "verynarrow":          # support of several hundred: the whole search runs streaming
+        x = (0.002 * rng.standard_normal((R, K))).astype(np.float32)
+    else:
+        x = _rows(rng, R, K, kind)
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    ent_ref = oracle_mod.entropy(p_ref)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    xt, dyt = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    p, supp, nnz, tau, ent, cols = _native.sparsemax_fwd(xt, want_nnz=True, want_tau=True,
+                                                         want_entropy=True, want_cols=True)
+    assert np.array_equal(supp.cpu().numpy(), s_ref)
+    assert np.array_equal(tau.cpu().numpy(), tau_ref)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    assert np.array_equal(nnz.cpu().numpy(), nnz_ref)
+    np.testing.assert_allclose(ent.cpu().numpy(), ent_ref, rtol=1e-6, atol=1e-7)
+    p2, supp2, _, _, _ = _native.sparsemax_fwd(xt)
+    assert np.array_equal(p2.cpu().numpy(), p_ref) and np.array_equal(supp2.cpu().numpy(), s_ref)
+    c = cols.cpu().numpy()
+    for r in range(R):
+        nz = np.flatnonzero(p_ref[r] > 0)
+        if c[r, 0] != -2:
+            assert nz.size <= c.shape[1]
+            assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
+        else:
+            assert nz.size > c.shape[1] or np.count_nonzero(x[r] > x[r].max() - 1) > 64
+    if kind == "normal":
+        assert np.all(c[:, 0] >= 0)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp), _native.sparsemax_bwd(dyt, p, supp)):
+        assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
