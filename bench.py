@@ -126,8 +126,10 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
         ev[i][0].record(); fwd(); ev[i][1].record(); bwd(); ev[i][2].record()
     barrier(world)
     wall = time.perf_counter() - t0
-    f_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
-    b_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    f_all = sorted(e[0].elapsed_time(e[1]) for e in ev)
+    b_all = sorted(e[1].elapsed_time(e[2]) for e in ev)
+    f_ms, b_ms = sum(f_all) / steps, sum(b_all) / steps
+    timed_sparsemax.last_median = (f_all[steps // 2], b_all[steps // 2])
     mean_supp = float(supp.float().mean().item())
     del p, dx
     return wall, f_ms, b_ms, mean_supp
@@ -372,10 +374,11 @@ def main():
     rows_total = a.rows * world * a.steps
     fwd_bytes = 8.0 * a.K * a.rows
     bwd_bytes = 12.0 * a.K * a.rows
+    f_med, b_med = timed_sparsemax.last_median
     kern = {
-        "sparsemax_fwd": {"ms": f_ms, "algorithmic_bytes": fwd_bytes,
+        "sparsemax_fwd": {"ms": f_ms, "ms_median": f_med, "algorithmic_bytes": fwd_bytes,
                           "GBps": fwd_bytes / (f_ms * 1e-3) / 1e9},
-        "sparsemax_bwd": {"ms": b_ms, "algorithmic_bytes": bwd_bytes,
+        "sparsemax_bwd": {"ms": b_ms, "ms_median": b_med, "algorithmic_bytes": bwd_bytes,
                           "GBps": bwd_bytes / (b_ms * 1e-3) / 1e9},
     }
     dom = "sparsemax_fwd" if f_ms >= b_ms else "sparsemax_bwd"
