@@ -45,7 +45,12 @@ int main(int argc, char** argv)
     if (!fwd || !bwd) { fprintf(stderr, "missing symbols\n"); return 1; }
     const size_t n = (size_t)R * K;
     float *x, *p, *dy, *dx; int32_t *supp, *cols;
-    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4));
+    // SMX_PAD=<bytes>: shift p (and dx) inside their allocations, to probe how the relative placement
+    // of the input and output streams affects the rate
+    const size_t pad = getenv("SMX_PAD") ? (size_t)atoll(getenv("SMX_PAD")) : 0;
+    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4 + pad));
+    p = (float*)((char*)p + pad); dx = (float*)((char*)dx + pad);
+    printf("x %p p %p dy %p dx %p\n", (void*)x, (void*)p, (void*)dy, (void*)dx);
     CK(hipMalloc(&supp, R * 4)); CK(hipMalloc(&cols, (size_t)R * cap * 4));
     uint32_t* mask = nullptr;
     if (K > 1024 && K <= 4096 && !getenv("SMX_NO_MASK")) CK(hipMalloc(&mask, (size_t)R * 512));
