@@ -47,7 +47,8 @@ int smlvm_last_hip_error(void);
  *   the divisor of the backward);  optional outputs (NULL to skip): nnz [R] int32 = #{p > 0},
  *   tau [R] fp32 (threshold in the max-shifted row), entropy [R] fp32 (lvmhelpers/marg.py:6-28).
  * p = max(x - max(x) - tau, 0).  dx = [p != 0] * (dy - sum(dy[p != 0]) / supp_size).
- * Inputs and outputs must not overlap.
+ * Inputs and outputs must not overlap.  Any K >= 1: rows of up to 65536 elements are held in
+ * registers (one read, one write); wider rows are streamed (three reads, one write).
  */
 int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
                         float* entropy, int64_t R, int32_t K, void* stream);
