@@ -302,16 +302,47 @@ struct Sm {
             int rank[NK];
 #pragma unroll
             for (int q = 0; q < NK; ++q) rank[q] = 0;
+            // first with "greater" alone (one compare + one add-with-carry per pair): exact unless
+            // two gains are equal, in which case two variables get the same rank
             for (int j0 = 0; j0 < n8; j0 += 8) {
                 double ej[8];
                 ld8(ee + j0, ej);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + u;
 #pragma unroll
-                    for (int q = 0; q < NK; ++q) {
-                        const int k = lane + 64 * q;
-                        rank[q] += ((ej[u] > ev[q]) || (ej[u] == ev[q] && j < k)) ? 1 : 0;
+                    for (int q = 0; q < NK; ++q) rank[q] += (ej[u] > ev[q]) ? 1 : 0;
+                }
+            }
+            // ranks of valid variables are distinct iff there was no tie: every variable claims its
+            // slot and looks who holds it afterwards
+            int* claim = reinterpret_cast<int*>(a2);
+            bool clash = false;
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int k = lane + 64 * q;
+                if (k < n) claim[rank[q]] = k;
+            }
+            wsync();
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int k = lane + 64 * q;
+                if (k < n) clash = clash || (claim[rank[q]] != k);
+            }
+            wsync();
+            if (__any(clash)) {   // rare: the full rule with the index tie-break
+#pragma unroll
+                for (int q = 0; q < NK; ++q) rank[q] = 0;
+                for (int j0 = 0; j0 < n8; j0 += 8) {
+                    double ej[8];
+                    ld8(ee + j0, ej);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = j0 + u;
+#pragma unroll
+                        for (int q = 0; q < NK; ++q) {
+                            const int k = lane + 64 * q;
+                            rank[q] += ((ej[u] > ev[q]) || (ej[u] == ev[q] && j < k)) ? 1 : 0;
+                        }
                     }
                 }
             }
