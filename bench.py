@@ -466,6 +466,24 @@ def main():
             xs, dys = gen(R, K, 1.0, dev, 5)
             w, fm, bm, _ = timed_sparsemax(native, xs, dys, 200, 20, 1, dev)
             small[f"{R}x{K}"] = {"fwd_us": fm * 1e3, "bwd_us": bm * 1e3, "pair_wall_us": w / 200 * 1e6}
+            # the same pair recorded once into a HIP graph (the C ABI allocates and synchronises
+            # nothing) and replayed: what a launch-bound inner loop would pay
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    pp, ss, _, _, _, cc = native.sparsemax_fwd(xs, want_cols=True)
+                    native.sparsemax_bwd_cols(dys, cc, pp, ss)
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                graph.replay()
+            torch.cuda.synchronize()
+            small[f"{R}x{K}"]["pair_graph_replay_us"] = (time.perf_counter() - t0) / 200 * 1e6
+            del graph
         out["model_shaped_latency"] = small
         out["compaction"] = [compaction_bench(native, dev, 1 << 20, 4096, a.sigma),
                              compaction_bench(native, dev, 1 << 20, 256, a.sigma),

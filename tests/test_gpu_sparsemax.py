@@ -379,3 +379,31 @@ def test_rows_wider_than_a_workgroup(dev, oracle_mod, R, K, kind):
     scale = np.abs(dy).max(axis=1, keepdims=True)
     for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp), _native.sparsemax_bwd(dyt, p, supp)):
         assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+
+
+def test_entry_points_capture_into_a_hip_graph(dev):
+    """The C-ABI calls allocate nothing and never synchronise, so a forward + list backward pair
+    records into a HIP graph (torch.cuda.CUDAGraph is hipGraph on ROCm; the output tensors come
+    from the graph's private pool) and replays on new inputs with the same result as eager calls."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(64, 256, device=dev, generator=g)
+    dy = torch.randn(64, 256, device=dev, generator=g)
+    _native.sparsemax_fwd(x, want_cols=True)            # load the library outside the capture
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            p, supp, _, _, _, cols = _native.sparsemax_fwd(x, want_cols=True)
+            dx = _native.sparsemax_bwd_cols(dy, cols, p, supp)
+    torch.cuda.current_stream().wait_stream(s)
+    for seed in (11, 12):
+        x.copy_(torch.randn(64, 256, device=dev, generator=g) * (1 + seed % 2))
+        dy.copy_(torch.randn(64, 256, device=dev, generator=g))
+        graph.replay()
+        torch.cuda.synchronize()
+        p_e, supp_e, _, _, _, cols_e = _native.sparsemax_fwd(x, want_cols=True)
+        dx_e = _native.sparsemax_bwd_cols(dy, cols_e, p_e, supp_e)
+        assert torch.equal(p, p_e) and torch.equal(supp, supp_e) and torch.equal(dx, dx_e)
