@@ -48,8 +48,15 @@ int main(int argc, char** argv)
     // SMX_PAD=<bytes>: shift p (and dx) inside their allocations, to probe how the relative placement
     // of the input and output streams affects the rate
     const size_t pad = getenv("SMX_PAD") ? (size_t)atoll(getenv("SMX_PAD")) : 0;
-    CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4 + pad));
-    p = (float*)((char*)p + pad); dx = (float*)((char*)dx + pad);
+    if (getenv("SMX_ARENA")) {   // one allocation, the four tensors back to back (+ pad between them)
+        char* arena;
+        CK(hipMalloc(&arena, 4 * (n * 4 + pad)));
+        x = (float*)arena; p = (float*)(arena + (n * 4 + pad)); dy = (float*)(arena + 2 * (n * 4 + pad));
+        dx = (float*)(arena + 3 * (n * 4 + pad));
+    } else {
+        CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4 + pad));
+        p = (float*)((char*)p + pad); dx = (float*)((char*)dx + pad);
+    }
     printf("x %p p %p dy %p dx %p\n", (void*)x, (void*)p, (void*)dy, (void*)dx);
     CK(hipMalloc(&supp, R * 4)); CK(hipMalloc(&cols, (size_t)R * cap * 4));
     uint32_t* mask = nullptr;
