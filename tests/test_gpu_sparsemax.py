@@ -407,3 +407,36 @@ def test_entry_points_capture_into_a_hip_graph(dev):
         p_e, supp_e, _, _, _, cols_e = _native.sparsemax_fwd(x, want_cols=True)
         dx_e = _native.sparsemax_bwd_cols(dy, cols_e, p_e, supp_e)
         assert torch.equal(p, p_e) and torch.equal(supp, supp_e) and torch.equal(dx, dx_e)
+
+
+@pytest.mark.parametrize("K", [1, 2, 31, 32, 33, 127, 128, 129, 256, 257, 512, 513, 1024, 1025, 2047, 2048,
+                               2049, 4095, 4097, 8191, 8193, 16384, 16385, 32769, 65535, 65536, 65537])
+def test_every_tile_boundary(dev, oracle_mod, K):
+    """One shape either side of every switch in the dispatch table (lane-group tiles, one row per
+    wave, workgroup tiles, streamed rows; 16-byte and scalar layouts): forward with all optional
+    outputs, support lists, both backward entry points, against the oracle."""
+    from lvmhelpers import _native
+    R = 5
+    rng = np.random.default_rng(K)
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    x[1] *= 0.05
+    x[2] = np.round(x[2] * 2) / 2
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    xt, dyt = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    p, supp, nnz, tau, ent, cols, mask = _native.sparsemax_fwd(
+        xt, want_nnz=True, want_tau=True, want_entropy=True, want_cols=True, want_mask=True)
+    assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(supp.cpu().numpy(), s_ref)
+    assert np.array_equal(tau.cpu().numpy(), tau_ref) and np.array_equal(nnz.cpu().numpy(), nnz_ref)
+    np.testing.assert_allclose(ent.cpu().numpy(), oracle_mod.entropy(p_ref), rtol=1e-6, atol=1e-7)
+    c = cols.cpu().numpy()
+    for r in range(R):
+        nz = np.flatnonzero(p_ref[r] > 0)
+        if c[r, 0] >= -1:
+            assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
+        else:
+            assert nz.size > c.shape[1] or K > 4096
+    scale = np.maximum(np.abs(dy).max(axis=1, keepdims=True), 1e-30)
+    for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp, mask), _native.sparsemax_bwd(dyt, p, supp)):
+        assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
