@@ -440,3 +440,27 @@ def test_every_tile_boundary(dev, oracle_mod, K):
     scale = np.maximum(np.abs(dy).max(axis=1, keepdims=True), 1e-30)
     for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp, mask), _native.sparsemax_bwd(dyt, p, supp)):
         assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+
+
+def test_calls_on_two_streams_do_not_interfere(dev):
+    """The entry points keep no state between calls: launches queued on two streams at once (each
+    with its own tensors) give the results of the same calls made one after the other."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(8)
+    xs = [torch.randn(20000, 1000, device=dev, generator=g) * s for s in (1.0, 0.1)]
+    dys = [torch.randn(20000, 1000, device=dev, generator=g) for _ in range(2)]
+    ref = []
+    for x, dy in zip(xs, dys):
+        p, supp, _, _, _, cols = _native.sparsemax_fwd(x, want_cols=True)
+        ref.append((p, _native.sparsemax_bwd_cols(dy, cols, p, supp)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [None, None]
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                p, supp, _, _, _, cols = _native.sparsemax_fwd(xs[i], want_cols=True)
+                out[i] = (p, _native.sparsemax_bwd_cols(dys[i], cols, p, supp))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1])
