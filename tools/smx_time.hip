@@ -54,7 +54,11 @@ int main(int argc, char** argv)
         x = (float*)arena; p = (float*)(arena + (n * 4 + pad)); dy = (float*)(arena + 2 * (n * 4 + pad));
         dx = (float*)(arena + 3 * (n * 4 + pad));
     } else {
-        CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4 + pad));
+        if (getenv("SMX_ORDER")) {   // the order bench.py allocates in: x, dy, then p, dx
+            CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dx, n * 4 + pad));
+        } else {
+            CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4 + pad)); CK(hipMalloc(&dy, n * 4)); CK(hipMalloc(&dx, n * 4 + pad));
+        }
         p = (float*)((char*)p + pad); dx = (float*)((char*)dx + pad);
     }
     printf("x %p p %p dy %p dx %p\n", (void*)x, (void*)p, (void*)dy, (void*)dx);
