@@ -14,6 +14,23 @@
 
 namespace smlvm {
 
+// LDS traffic of one lane group stays inside one wave (G divides 64), and a wave's LDS operations
+// execute in order: this only pins the compiler's order and re-converges the wave.
+__device__ __forceinline__ void group_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lane T of every 16-lane DPP row, broadcast to the whole row (DPP row_newbcast, gfx90a and later)
+template <int T>
+__device__ __forceinline__ float row_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                                 0x150 + T, 0xf, 0xf, false));
+}
+
 template <int G, int W>
 __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restrict__ scores,
                                                           float* __restrict__ configs,
@@ -24,6 +41,9 @@ __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restric
     __shared__ float s_score[256];
     __shared__ int s_src[256];
     __shared__ uint32_t s_cfg[256 * W];
+    // the sample's scores, staged once: the DP below is n dependent steps, and a global load per
+    // step (~1 us each) was most of its time
+    __shared__ float s_x[GPB * 32 * W];
 
     const int lane = threadIdx.x % G;
     const int grp = threadIdx.x / G;
@@ -36,7 +56,10 @@ __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restric
     uint32_t cfg[W];
 #pragma unroll
     for (int w = 0; w < W; ++w) cfg[w] = 0u;
-    const float x0 = x[0];
+    float* sx = s_x + grp * 32 * W;
+    for (int i = lane; i < n; i += G) sx[i] = x[i];
+    group_lds_sync();
+    const float x0 = sx[0];
     const float c1 = 0.0f + x0;  // c0.update(0, x[0]), binary_topk.h:104-107
     const bool on_first = x0 >= 0.0f;  // binary_topk.h:110-116
     float a = -INFINITY;
@@ -45,24 +68,41 @@ __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restric
     int L = 2;
 
     for (int i = 1; i < n; ++i) {
-        const float xi = x[i];
+        const float xi = sx[i];
         const float b = a + xi;
         int cntA = 0, cntB = 0;
-        for (int t = 0; t < L; ++t) {
-            const float at = __shfl(a, t, G);
-            const float bt = at + xi;
-            cntA += (bt > a) ? 1 : 0;
-            cntB += (at >= b) ? 1 : 0;
+        if constexpr (G == 16) {
+            // a lane group is one DPP row: entry t reaches the other 15 lanes with row_newbcast
+            // (one VALU instruction) instead of a ds_bpermute round trip through the LDS
+#define SMLVM_TOPK_STEP(T)                                                    \
+            if (T < L) {                                                      \
+                const float at = row_bcast<T>(a);                             \
+                const float bt = at + xi;                                     \
+                cntA += (bt > a) ? 1 : 0;                                     \
+                cntB += (at >= b) ? 1 : 0;                                    \
+            }
+            SMLVM_TOPK_STEP(0) SMLVM_TOPK_STEP(1) SMLVM_TOPK_STEP(2) SMLVM_TOPK_STEP(3)
+            SMLVM_TOPK_STEP(4) SMLVM_TOPK_STEP(5) SMLVM_TOPK_STEP(6) SMLVM_TOPK_STEP(7)
+            SMLVM_TOPK_STEP(8) SMLVM_TOPK_STEP(9) SMLVM_TOPK_STEP(10) SMLVM_TOPK_STEP(11)
+            SMLVM_TOPK_STEP(12) SMLVM_TOPK_STEP(13) SMLVM_TOPK_STEP(14) SMLVM_TOPK_STEP(15)
+#undef SMLVM_TOPK_STEP
+        } else {
+            for (int t = 0; t < L; ++t) {
+                const float at = __shfl(a, t, G);
+                const float bt = at + xi;
+                cntA += (bt > a) ? 1 : 0;
+                cntB += (at >= b) ? 1 : 0;
+            }
         }
         const int rA = lane + cntA, rB = lane + cntB;
         if (lane < L && rA < k) { gs[rA] = a; gi[rA] = lane; }
         if (lane < L && rB < k) { gs[rB] = b; gi[rB] = lane | 0x100; }
-        __syncthreads();
+        group_lds_sync();   // a group never spans waves: no workgroup barrier in the n-step loop
         const int Ln = (2 * L < k) ? 2 * L : k;
         float na = -INFINITY;
         int src = lane;
         if (lane < Ln) { na = gs[lane]; src = gi[lane]; }
-        __syncthreads();
+        group_lds_sync();
         const int sl = src & 0xff;
         const uint32_t bit = (src & 0x100) ? (1u << (i & 31)) : 0u;
         const int wi = i >> 5;
@@ -79,7 +119,7 @@ __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restric
     uint32_t* gc = s_cfg + grp * G * W;
 #pragma unroll
     for (int w = 0; w < W; ++w) gc[lane * W + w] = cfg[w];
-    __syncthreads();
+    group_lds_sync();
     if (live) {
         float* out = configs + sample * (int64_t)k * n;
         const int total = k * n;
