@@ -812,6 +812,11 @@ static int launch_sm_fwd(const SmArgs& a, int resume)
 
 // Tier sizes for 64 < n <= 128 (LDS per sample 40.5 KB -> 4 per CU, 81.7 KB -> 2 per CU, 158 KB -> 1)
 constexpr int kTier1 = 64, kTier2 = 94, kTier3 = SMLVM_SPARSEMAP_MAX_BITS + 2;
+// Tier 0, only for batches that oversubscribe the chip at four samples per CU: 20 KB per sample ->
+// eight per CU, i.e. two waves per SIMD, which hides part of the dependent-instruction latency
+// that a lone wave per SIMD is exposed to; samples whose active set outgrows 38 entries move on.
+constexpr int kTier0 = 40;
+static_assert(SmLayout<kTier0, 4, 2>::total <= 20 * 1024, "tier 0: eight samples per CU");
 static_assert(SmLayout<kTier1, 4, 2>::total <= 40 * 1024, "tier 1: four samples per CU");
 static_assert(SmLayout<kTier2, 4, 2>::total <= 80 * 1024, "tier 2: two samples per CU");
 
@@ -857,7 +862,21 @@ extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_score
     a.ws_vec = reinterpret_cast<double*>(w);
     w += align256(sizeof(double) * 3 * ldo * (size_t)B);
     if (!inv_a) a.a_out = reinterpret_cast<double*>(w);
-    int rc = launch_sm_fwd<kTier1, 4, 2>(a, 0);
+    static thread_local int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    int rc;
+    if (B > 4 * (int64_t)cus) {
+        rc = launch_sm_fwd<kTier0, 4, 2>(a, 0);
+        if (rc != SMLVM_OK) return rc;
+        rc = launch_sm_fwd<kTier1, 4, 2>(a, 1);
+    } else {
+        rc = launch_sm_fwd<kTier1, 4, 2>(a, 0);
+    }
     if (rc != SMLVM_OK) return rc;
     if (n + 2 <= kTier2) return launch_sm_fwd<kTier2, 4, 2>(a, 1);
     rc = launch_sm_fwd<kTier2, 4, 2>(a, 1);
