@@ -834,7 +834,13 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
 // streamed at all: each non-zero of p fetches its own element (one 64/128-byte sector per support
 // element instead of 4K bytes per row).  `nz` must be wave-uniformly known to be small by the
 // caller; per register the ballot skips the load unless some lane has a non-zero there.
-constexpr int kGatherMaxSupport = 96;   // ~ where 128-byte sectors per element reach the 4K-byte row
+constexpr int kGatherMaxSupport = 96;   // ~ where 128-byte sectors per element reach a 16 KB row
+// ... and for shorter rows where one 64-byte sector per element reaches the row itself
+__device__ __forceinline__ int gather_max(int K)
+{
+    const int byrow = K >> 4;
+    return byrow < kGatherMaxSupport ? byrow : kGatherMaxSupport;
+}
 
 // a[]: in = the row of p, out = the row of dx.  The gathered dy values replace the non-zeros of p
 // in place (one register array; a 64-bit per-lane mask remembers where they are), zeros stay
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_waves_per_eu(E)) void spar
     if (!live) row = R - 1;
     const int s = supp[row];
     WaveRed<G> red;
-    if (__ballot(s > kGatherMaxSupport) == 0ull) {   // every row of this wave has a small support
+    if (__ballot(s > gather_max(K)) == 0ull) {   // every row of this wave has a small support
         float a[E];
         load_row<E, VEC, FULL>(p + row * K, K, gl, G, a, 0.0f);
         bwd_row_gather<E, VEC>(dy + row * K, gl, G, a, s, red);
@@ -1182,7 +1188,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
     if constexpr (MASKS) {
         // no list, but the forward left the non-zero pattern (head and s are wave-uniform here)
-        if (mask && head == kColsMask && s <= kGatherMaxSupport) {
+        if (mask && head == kColsMask && s <= gather_max(K)) {
             const uint2 m = reinterpret_cast<const uint2*>(mask + row * kMaskWordsPerRow)[lane];
             float a[E];
 #pragma unroll
@@ -1200,7 +1206,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
         } else {
             bwd_row_from_cols<E, G, VEC, FULL>(dy + row * K, dx + row * K, list, cap, K, gl, s, live, red);
         }
-    } else if (__ballot(s > kGatherMaxSupport) == 0ull) {
+    } else if (__ballot(s > gather_max(K)) == 0ull) {
         float a[E];
         load_row<E, VEC, FULL>(p + row * K, K, gl, G, a, 0.0f);
         bwd_row_gather<E, VEC>(dy + row * K, gl, G, a, s, red);
