@@ -51,6 +51,50 @@ def parse():
     return ap.parse_args()
 
 
+def child_command(n_gpus, argv, port):
+    """The command the parent starts for `--gpus N` when it was not itself started by a launcher:
+    one rank per GPU of this node over RCCL (the driver's own multi-GPU command line)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks as a
+    CHILD process (this parent never touches the GPU, and never replaces itself), relay rank 0's
+    JSON line and leave with the child's exit code -- a failed rank makes the whole run fail."""
+    import subprocess
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} asked for, {have} visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(child_command(a.gpus, argv, _free_port()), env=env, stdout=subprocess.PIPE,
+                          text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {a.gpus}-rank run failed (exit {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != a.gpus:
+        print("bench.py: the child reported a different rank count", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
 def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,8 +130,49 @@ def max_over_ranks(x, world, dev):
     return float(t.item())
 
 
+def gather_max(K):
+    """Support size up to which the p-based backward gathers dy instead of streaming it
+    (csrc/sparsemax.hip gather_max / kGatherMaxSupport)."""
+    return min(K >> 4, 96)
+
+
+def min_traffic(K, cap, cols, supp, has_mask):
+    """Least HBM bytes one launch has to move, per kernel, given what the rows turned out to be:
+      forward        read x, write p, supp and the support list: 8K + 4 + 4 cap per row
+                     (+ 512 B for a row that leaves a support mask)
+      backward       row with a list:  write dx, read list + supp, one 64 B sector of dy per listed
+                                       column: 4K + 4 cap + 4 + 64 s
+                     row with a mask:  4K + 512 + 64 + 4 + 64 s
+                     no list, s <= gather_max: read p, write dx, gather dy: 8K + 4 + 64 s
+                     otherwise: stream dy and p, write dx: 12K + 4
+    These are the denominators of every `frac` below (never the 20 K model, which the list backward
+    undercuts by not reading p or dy at all)."""
+    R = supp.shape[0]
+    head = cols[:, 0]
+    s = supp.to(torch.float64)
+    listed = head >= -1
+    masked = (head == -3) & (supp <= gather_max(K)) if has_mask else torch.zeros_like(listed)
+    gath = ~listed & ~masked & (supp <= gather_max(K))
+    stream = ~listed & ~masked & ~gath
+    n_masked_fwd = int((head == -3).sum().item()) if has_mask else 0
+    fwd = R * (8.0 * K + 4 + 4 * cap) + 512.0 * n_masked_fwd
+    bwd = (float(listed.sum().item()) * (4.0 * K + 4 * cap + 4) + 64.0 * float(s[listed].sum().item())
+           + float(masked.sum().item()) * (4.0 * K + 512 + 64 + 4) + 64.0 * float(s[masked].sum().item())
+           + float(gath.sum().item()) * (8.0 * K + 4) + 64.0 * float(s[gath].sum().item())
+           + float(stream.sum().item()) * (12.0 * K + 4))
+    return {"fwd": fwd, "bwd": bwd,
+            "rows": {"listed": int(listed.sum().item()), "masked": int(masked.sum().item()),
+                     "gather": int(gath.sum().item()), "stream": int(stream.sum().item())}}
+
+
+def checksum64(t):
+    """Order-independent 8-byte checksum of a tensor's bits (wrapping int64 sum of its 32-bit words)."""
+    return int(t.view(torch.int32).sum(dtype=torch.int64).item())
+
+
 def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
-    """Returns (wall seconds for `steps` fwd+bwd passes, mean fwd ms, mean bwd ms)."""
+    """`steps` fwd+bwd passes.  Returns a dict: wall seconds, mean/median fwd and bwd ms (HIP events
+    on the launch stream), mean support, the least-traffic model of both launches and checksums."""
     R, K = x.shape
     p = torch.empty_like(x)
     dx = torch.empty_like(x)
@@ -98,7 +183,7 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
     import ctypes
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     mbytes = L.smlvm_sparsemax_support_mask_bytes(ctypes.c_int64(R), ctypes.c_int32(K))
-    mask = torch.empty(mbytes // 4, dtype=torch.int32, device=dev) if mbytes else None
+    mask = torch.zeros(mbytes // 4, dtype=torch.int32, device=dev) if mbytes else None
     mp = ctypes.c_void_p(mask.data_ptr()) if mask is not None else None
 
     # the pair lvmhelpers.functional.sparsemax runs: the forward also lists each row's support
@@ -128,11 +213,13 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
     wall = time.perf_counter() - t0
     f_all = sorted(e[0].elapsed_time(e[1]) for e in ev)
     b_all = sorted(e[1].elapsed_time(e[2]) for e in ev)
-    f_ms, b_ms = sum(f_all) / steps, sum(b_all) / steps
-    timed_sparsemax.last_median = (f_all[steps // 2], b_all[steps // 2])
-    mean_supp = float(supp.float().mean().item())
+    res = {"wall": wall, "fwd_ms": sum(f_all) / steps, "bwd_ms": sum(b_all) / steps,
+           "fwd_ms_median": f_all[steps // 2], "bwd_ms_median": b_all[steps // 2],
+           "launches": steps, "mean_support": float(supp.float().mean().item()),
+           "min_traffic": min_traffic(K, cap, cols, supp, mask is not None),
+           "checksum_p": checksum64(p), "checksum_dx": checksum64(dx)}
     del p, dx
-    return wall, f_ms, b_ms, mean_supp
+    return res
 
 
 def gen(R, K, sigma, dev, seed):
@@ -234,30 +321,32 @@ def topk_bench(native, dev, B, n, k, reps=20, cpu=True):
     return out
 
 
-def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
+def median_ms(fn, launches=20, warm=5):
+    """SURVEY.md 8(d) timing method: HIP-event pairs around each of >= 20 launches after 5 warm-ups,
+    median (events on torch's current stream, which is the stream every call here launches on)."""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(launches)]
+    for e0, e1 in ev:
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    t = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return t[launches // 2]
+
+
+def sparsemap_bench(native, dev, B, n, budget, sigma, reps=20, world=1, seed=77):
     g = torch.Generator(device=dev).manual_seed(seed)
     x = torch.randn(B, n, device=dev, generator=g) * sigma
     init = torch.rand(B, 2 * n, dtype=torch.double,
                       generator=torch.Generator().manual_seed(42)).to(dev)
     out = native.sparsemap_fwd(x, init, budget, 300)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        out = native.sparsemap_fwd(x, init, budget, 300)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = median_ms(lambda: native.sparsemap_fwd(x, init, budget, 300), reps, 2)
     dp = torch.randn(B, n + 1, device=dev, generator=g)
-    e0.record()
-    for _ in range(reps):
-        native.sparsemap_bwd(dp, out["aset_bits"], out["alen"], out["inv_a"], n)
-    e1.record()
-    torch.cuda.synchronize()
-    bms = e0.elapsed_time(e1) / reps
+    bms = median_ms(lambda: native.sparsemap_bwd(dp, out["aset_bits"], out["alen"], out["inv_a"], n), reps, 2)
     iters = float(out["iters"].double().sum().item())
     res = {"B": B, "bits": n, "budget": budget, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
-           "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
+           "launches": reps, "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
            "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
            "converged_frac": float((out["status"] != 1).float().mean().item())}
     if _dist_on():  # whole-job figures: every rank solves its own B samples, slowest rank counts
@@ -267,49 +356,64 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=5, world=1, seed=77):
     return res
 
 
-def compaction_bench(native, dev, R, K, sigma, reps=5):
-    """Kernel 2 on the probabilities of a forward pass: support_count, support_offsets,
-    support_compact and the weighted loss reduction, each against its algorithmic HBM bytes
-    (count 4KR read; compact 4KR + 12N + 8(R+1); reduce 12N read)."""
+def compaction_bench(native, dev, R, K, sigma):
+    """Kernel 2 on the probabilities of a forward pass, every launch through the C ABI on
+    preallocated buffers (median of 20): support_count, support_offsets, support_compact, their
+    list-fed forms and the weighted loss reduction, each against the bytes it has to move
+    (count 4KR read + 4R; compact 4KR + 12N + 8(R+1); list-fed 4 cap R + 12N +
+    8(R+1) + one 64-byte sector per gathered probability; reduce 8N read of vals and comps)."""
+    import ctypes
     x, _ = gen(R, K, sigma, dev, 4321)
     p, supp, nnz, _, _, lists = native.sparsemax_fwd(x, want_nnz=True, want_cols=True)
     del x
+    L = native.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
+    cap = lists.shape[1]
+    i64, i32 = ctypes.c_int64, ctypes.c_int32
+    off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    ws_b = L.smlvm_support_offsets_workspace_bytes(i64(R))
+    ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+    nnz2 = torch.empty_like(nnz)
 
-    def timeit(fn):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+    def ok(rc):
+        assert rc == 0, rc
 
-    t_count = timeit(lambda: native.support_count(p))
-    t_off = timeit(lambda: native.support_offsets(nnz))
-    off, rows, cols, vals = native.support_compact(p, nnz)
-    N = int(rows.shape[0])
-    t_all = timeit(lambda: native.support_compact(p, nnz))       # offsets + one sync + compact
+    t_count = median_ms(lambda: ok(L.smlvm_support_count(P(p), P(nnz2), i64(R), i32(K), st)))
+    t_count_l = median_ms(lambda: ok(L.smlvm_support_count_cols(P(p), P(lists), i32(cap), P(nnz2), i64(R), i32(K), st)))
+    t_off = median_ms(lambda: ok(L.smlvm_support_offsets(P(nnz), P(off), i64(R), P(ws), ctypes.c_size_t(ws_b), st)))
+    N = int(off[R].item())
+    rows = torch.empty(N, dtype=torch.int32, device=dev)
+    cols = torch.empty(N, dtype=torch.int32, device=dev)
+    vals = torch.empty(N, dtype=torch.float32, device=dev)
+    t_comp = median_ms(lambda: ok(L.smlvm_support_compact(P(p), P(off), P(rows), P(cols), P(vals), i64(R), i32(K), st)))
+    t_comp_l = median_ms(lambda: ok(L.smlvm_support_compact_cols(P(p), P(lists), i32(cap), P(off), P(rows), P(cols), P(vals), i64(R), i32(K), st)))
     comps = torch.rand(N, device=dev) * 500
-    t_red = timeit(lambda: native.weighted_loss_reduce_fwd(vals, comps, off, 1.0 / R))
-    t_compact = max(t_all - t_off, 1e-6)
-    gb = lambda b, ms: b / (ms * 1e-3) / 1e9
-    # the same from the forward's support lists: count + offsets + sync + compact, no pass over p
-    t_lists = timeit(lambda: native.support_compact(p, support_cols=lists))
-    fused_bytes = 12.0 * N + 8.0 * (R + 1) + 2 * 4.0 * lists.shape[1] * R
-    return {"R": R, "K": K, "N": N,
-            "from_support_lists": {"ms_count_offsets_compact": t_lists,
-                                   "ms_scan_count_offsets_compact": t_count + t_all,
-                                   "algorithmic_bytes": fused_bytes,
-                                   "note": "what the Marginalizer / top-k paths run: rows listed by the "
-                                           "forward are counted and compacted from <= cap entries"},
-            "support_count": {"ms": t_count, "GBps": gb(4.0 * K * R, t_count)},
-            "support_offsets": {"ms": t_off},
-            "support_compact": {"ms": t_compact, "GBps": gb(4.0 * K * R + 12.0 * N + 8.0 * (R + 1), t_compact),
-                                "note": "offsets launch subtracted; includes the one host sync that sizes the lists"},
-            "weighted_loss_reduce_fwd": {"ms": t_red, "GBps": gb(12.0 * N, t_red)},
-            "frac_of_hbm_peak_count": gb(4.0 * K * R, t_count) / HBM_PEAK_GBS,
-            "frac_of_hbm_peak_compact": gb(4.0 * K * R + 12.0 * N + 8.0 * (R + 1), t_compact) / HBM_PEAK_GBS}
+    total = torch.empty(1, dtype=torch.float32, device=dev)
+    wr_b = L.smlvm_weighted_loss_reduce_workspace_bytes(i64(N))
+    wr = torch.empty(wr_b, dtype=torch.uint8, device=dev)
+    t_red = median_ms(lambda: ok(L.smlvm_weighted_loss_reduce_fwd(
+        P(vals), P(comps), None, None, P(total), ctypes.c_float(1.0 / R), i64(0), i64(N), P(wr),
+        ctypes.c_size_t(wr_b), st)))
+    # what the Python modules pay end to end: count + offsets + ONE host sync (sizes the lists) + compact
+    t_e2e = median_ms(lambda: native.support_compact(p, support_cols=lists), 10, 2)
+    listed = float((lists[:, 0] >= -1).float().mean().item())
+
+    def entry(ms, nbytes):
+        g = nbytes / (ms * 1e-3) / 1e9
+        return {"ms": ms, "bytes": nbytes, "GBps": g, "frac": g / HBM_PEAK_GBS}
+
+    return {"R": R, "K": K, "sigma": sigma, "N": N, "rows_with_list": listed, "launches": 20,
+            "support_count": entry(t_count, 4.0 * K * R + 4.0 * R),
+            "support_offsets": entry(t_off, 4.0 * R + 8.0 * (R + 1)),
+            "support_compact": entry(t_comp, 4.0 * K * R + 12.0 * N + 8.0 * (R + 1)),
+            "support_count_cols": entry(t_count_l, listed * 4.0 * cap * R + (1 - listed) * 4.0 * K * R + 4.0 * R),
+            "support_compact_cols": entry(t_comp_l, listed * (4.0 * cap * R + 64.0 * N) + (1 - listed) * 4.0 * K * R
+                                          + 12.0 * N + 8.0 * (R + 1)),
+            "weighted_loss_reduce_fwd": entry(t_red, 8.0 * N),
+            "python_support_compact_from_lists_ms": t_e2e,
+            "note": "frac = bytes the launch has to move / time / 8 TB/s; the list-fed forms read the "
+                    "forward's support lists instead of p (64-byte sector per gathered probability)"}
 
 
 def train_steps_bench(dev, world, rank):
@@ -360,26 +464,55 @@ def train_steps_bench(dev, world, rank):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))     # parent of the N ranks: no GPU call in here
     world, rank, local = dist_setup(a.gpus)
+    if world != a.gpus and not (a.gpus == 1 and world == 1):
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device("cuda", local if _dist_on() else 0)
     from lvmhelpers import _native as native
     native.lib()
 
     x, dy = gen(a.rows, a.K, a.sigma, dev, 1234 + rank)
-    wall, f_ms, b_ms, mean_supp = timed_sparsemax(native, x, dy, a.steps, a.warmup, world, dev)
-    wall = max_over_ranks(wall, world, dev)
+    tm = timed_sparsemax(native, x, dy, a.steps, a.warmup, world, dev)
+    wall = max_over_ranks(tm["wall"], world, dev)
+    f_ms, b_ms = tm["fwd_ms"], tm["bwd_ms"]
     del x, dy
     torch.cuda.empty_cache()
 
+    # proof that N ranks took part and that their shards differ (rank r generates seed 1234 + r,
+    # so rank 0's checksums are the same at every N and equal the 1-GPU run's)
+    ranks_seen, checks, rccl = 1, [[tm["checksum_p"], tm["checksum_dx"]]], None
+    if _dist_on():
+        import torch.distributed as dist
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        mine = torch.tensor([tm["checksum_p"], tm["checksum_dx"]], dtype=torch.int64, device=dev)
+        allc = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allc, mine)
+        checks = [[int(v) for v in t.tolist()] for t in allc]
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+
     rows_total = a.rows * world * a.steps
-    fwd_bytes = 8.0 * a.K * a.rows
-    bwd_bytes = 12.0 * a.K * a.rows
-    f_med, b_med = timed_sparsemax.last_median
+    fwd_alg = 8.0 * a.K * a.rows               # read x + write p
+    mt = tm["min_traffic"]
+    gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
     kern = {
-        "sparsemax_fwd": {"ms": f_ms, "ms_median": f_med, "algorithmic_bytes": fwd_bytes,
-                          "GBps": fwd_bytes / (f_ms * 1e-3) / 1e9},
-        "sparsemax_bwd": {"ms": b_ms, "ms_median": b_med, "algorithmic_bytes": bwd_bytes,
-                          "GBps": bwd_bytes / (b_ms * 1e-3) / 1e9},
+        "sparsemax_fwd": {"ms": f_ms, "ms_median": tm["fwd_ms_median"], "algorithmic_bytes": fwd_alg,
+                          "GBps": gbps(fwd_alg, f_ms), "min_traffic_bytes": mt["fwd"],
+                          "frac": gbps(mt["fwd"], f_ms) / HBM_PEAK_GBS},
+        "sparsemax_bwd": {"ms": b_ms, "ms_median": tm["bwd_ms_median"], "min_traffic_bytes": mt["bwd"],
+                          "GBps": gbps(mt["bwd"], b_ms), "frac": gbps(mt["bwd"], b_ms) / HBM_PEAK_GBS,
+                          "streaming_model_bytes": 12.0 * a.K * a.rows,
+                          "note": "GBps and frac are on the bytes this launch has to move (dx written, "
+                                  "support list + one 64-byte sector of dy per support element read), "
+                                  "not on SURVEY.md's 12 K streaming model, which it undercuts by "
+                                  "reading neither p nor the dy row"},
     }
     dom = "sparsemax_fwd" if f_ms >= b_ms else "sparsemax_bwd"
     traffic = None
@@ -394,6 +527,7 @@ def main():
                     kern[k]["hbm_GBps"] = kern[k]["hbm_traffic_bytes"] / (kern[k]["ms"] * 1e-3) / 1e9
         except Exception:
             traffic = None
+    dom_bytes = fwd_alg if dom == "sparsemax_fwd" else mt["bwd"]
     out = {
         "metric": "sparsemax_fwd_bwd_rows_per_sec",
         "value": rows_total / wall,
@@ -409,19 +543,22 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"synthetic sparsemax fwd+bwd sweep, {a.rows} rows/GPU x K={a.K} fp32, "
                                f"logits N(0,{a.sigma}^2) (BASELINE.json configs[2])",
-                   "rows_per_gpu": a.rows, "K": a.K, "mean_support": mean_supp,
+                   "rows_per_gpu": a.rows, "K": a.K, "mean_support": tm["mean_support"],
                    "parallelism": f"rows sharded over {world} GPU(s), no collective"},
-        "fwd_bwd_GBps_per_gpu": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9,
-        "fwd_bwd_frac_of_hbm_peak": (fwd_bytes + bwd_bytes) / ((f_ms + b_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["GBps"],
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["GBps"] / HBM_PEAK_GBS,
+        "ranks_seen": ranks_seen,
+        "rank_checksums_p_dx": checks,
+        "rccl_version": rccl,
+        "fwd_bwd_min_traffic_GBps_per_gpu": gbps(mt["fwd"] + mt["bwd"], f_ms + b_ms),
+        "fwd_bwd_frac": gbps(mt["fwd"] + mt["bwd"], f_ms + b_ms) / HBM_PEAK_GBS,
+        "backward_rows": mt["rows"],
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": gbps(dom_bytes, kern[dom]["ms"]),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": gbps(dom_bytes, kern[dom]["ms"]) / HBM_PEAK_GBS,
                      "traffic": traffic,
-                     "note": "achieved = algorithmic bytes (fwd 8K, bwd 12K per row) / measured time. The "
-                             "forward also writes each row's support list (<= 32 columns); the backward "
-                             "reads that list, gathers dy at those columns and writes dx without reading p "
-                             "or streaming dy, so its HBM traffic (PMC, profiles/traffic.json) is about a "
-                             "third of its algorithmic bytes; see `kernels` for both launches (`hbm_GBps` "
-                             "= PMC traffic / time)."},
+                     "note": "dominant kernel; achieved = algorithmic bytes per launch (forward: 8 K per "
+                             "row, SURVEY.md 8(d)) / mean launch time by HIP events in the timed region. "
+                             "`fwd_bwd_frac` and kernels.*.frac use the least bytes each launch has to "
+                             "move (min_traffic in bench.py), so no fraction here can exceed 1."},
         "kernels": kern,
     }
 
@@ -442,16 +579,24 @@ def main():
 
         def sweep_entry(tag, K, R, chunks, make):
             xs, dys = make()
-            w, fm, bm, ms_ = timed_sparsemax(native, xs, dys, max(3, a.steps // 4), 2, 1, dev)
+            t = timed_sparsemax(native, xs, dys, 20, 5, 1, dev)   # 8(d): >= 20 launches, median
             del xs, dys
             torch.cuda.empty_cache()
-            gb = 20.0 * K * R / ((fm + bm) * 1e-3) / 1e9
-            sweep[tag] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "fwd_ms": fm,
-                          "bwd_ms": bm, "rows_per_s": R / ((fm + bm) * 1e-3), "GBps": gb,
-                          "frac_of_hbm_peak": gb / HBM_PEAK_GBS, "mean_support": ms_}
+            fm, bm_ = t["fwd_ms_median"], t["bwd_ms_median"]
+            m = t["min_traffic"]
+            sweep[tag] = {"rows_per_launch": R, "launches_per_1M_rows": chunks, "launches": 20,
+                          "fwd_ms": fm, "bwd_ms": bm_, "rows_per_s": R / ((fm + bm_) * 1e-3),
+                          "fwd_frac": gbps(m["fwd"], fm) / HBM_PEAK_GBS,
+                          "bwd_frac": gbps(m["bwd"], bm_) / HBM_PEAK_GBS,
+                          "fwd_bwd_frac": gbps(m["fwd"] + m["bwd"], fm + bm_) / HBM_PEAK_GBS,
+                          "min_traffic_bytes": m["fwd"] + m["bwd"],
+                          "rate_on_20K_model_GBps": gbps(20.0 * K * R, fm + bm_),
+                          "backward_rows": m["rows"], "mean_support": t["mean_support"]}
 
         # K in {256, 4096, 65536} x {N(0,1), N(0,0.05^2), adversarial}; the
-        # headline line above is (4096, N(0,1)).  GBps is against the algorithmic 20 K bytes/row.
+        # headline line above is (4096, N(0,1)).  Fractions are on the least bytes the two launches
+        # have to move (see min_traffic); rate_on_20K_model_GBps is SURVEY.md's streaming model and
+        # may exceed the HBM peak because the list backward reads neither p nor dy.
         for K, R, chunks in ((256, 1 << 20, 1), (4096, 1 << 20, 1), (65536, 1 << 15, 32)):
             if K != a.K or a.sigma != 1.0:
                 sweep_entry(f"K{K}", K, R, chunks, lambda: gen(R, K, 1.0, dev, 99))
@@ -464,8 +609,9 @@ def main():
         small = {}
         for R, K in ((64, 10), (64, 256)):
             xs, dys = gen(R, K, 1.0, dev, 5)
-            w, fm, bm, _ = timed_sparsemax(native, xs, dys, 200, 20, 1, dev)
-            small[f"{R}x{K}"] = {"fwd_us": fm * 1e3, "bwd_us": bm * 1e3, "pair_wall_us": w / 200 * 1e6}
+            t = timed_sparsemax(native, xs, dys, 200, 20, 1, dev)
+            small[f"{R}x{K}"] = {"fwd_us": t["fwd_ms"] * 1e3, "bwd_us": t["bwd_ms"] * 1e3,
+                                 "pair_wall_us": t["wall"] / 200 * 1e6}
             # the same pair recorded once into a HIP graph (the C ABI allocates and synchronises
             # nothing) and replayed: what a launch-bound inner loop would pay
             side = torch.cuda.Stream()
@@ -491,12 +637,11 @@ def main():
         out["binary_topk"] = [topk_bench(native, dev, 64, 32, 10, cpu=not a.no_cpu),
                               topk_bench(native, dev, 64, 128, 10, cpu=not a.no_cpu),
                               topk_bench(native, dev, 8192, 128, 10, cpu=not a.no_cpu)]
-        out["sparsemap"] = [sparsemap_bench(native, dev, 64, 32, 0, 1.0),
-                            sparsemap_bench(native, dev, 64, 32, 16, 1.0),
-                            sparsemap_bench(native, dev, 1024, 128, 0, 1.0),
-                            sparsemap_bench(native, dev, 1024, 128, 64, 1.0),
-                            sparsemap_bench(native, dev, 1024, 128, 0, 3.0),
-                            sparsemap_bench(native, dev, 8192, 128, 0, 1.0)]
+        # sigma in {1, 3} x (B, n) in {(64, 32), (8192, 128)} x budget in {0, n/2}
+        # (+ the 1024-sample per-GPU shard of config 5)
+        out["sparsemap"] = [sparsemap_bench(native, dev, B, n, bud, sg)
+                            for (B, n) in ((64, 32), (1024, 128), (8192, 128))
+                            for bud in (0, n // 2) for sg in (1.0, 3.0)]
     if _dist_on() and not a.no_sweep:
         # cfg5: batch 8192 over 8 GPUs = 1024 samples per rank at 128 bits; samples sharded, no collective
         out["sparsemap"] = [sparsemap_bench(native, dev, 1024, 128, 0, 1.0, world=world, seed=77 + rank),

@@ -30,6 +30,9 @@ namespace smlvm {
 // the per-element compare masks from having to stay alive (in SGPRs) from one pass to the next.
 template <int G>
 struct WaveRed {
+    // position of this lane among the lanes that hold the row, and how many there are
+    __device__ __forceinline__ int idx() const { return (int)(threadIdx.x & 63) % G; }
+    __device__ __forceinline__ int stride() const { return G; }
     __device__ __forceinline__ float max(float v) { return group_reduce<G>(v, OpMaxF{}); }
     __device__ __forceinline__ float min(float v) { return group_reduce<G>(v, OpMinF{}); }
     __device__ __forceinline__ int sum(int v) { return group_reduce<G>(v, OpSum{}); }
@@ -62,6 +65,8 @@ struct BlockRed {
     unsigned long long* base;
     int phase;
     __device__ __forceinline__ BlockRed(unsigned long long* lds) : base(lds), phase(0) {}
+    __device__ __forceinline__ int idx() const { return (int)threadIdx.x; }
+    __device__ __forceinline__ int stride() const { return 64 * NW; }
     __device__ __forceinline__ unsigned long long* next_set()
     {
         unsigned long long* s = base + phase * NW * kSlots;
@@ -160,6 +165,25 @@ struct BlockRed {
 };
 
 // ------------------------------------------------------------------------------- exact edge
+// The oracle's support size is the NUMBER of ranks j = 1..K whose fp32 test
+//     (float)j * z_(j)  >  (float)S_j - 1.0f          (S_j: fp64 prefix sum of the sorted row)
+// holds, and tau = ((float)S_s - 1)/s with S_s the prefix sum at that count.  In exact arithmetic
+// f(j) = 1 + j z_(j) - S_j is non-increasing, constant inside a group of tied values, positive on
+// the support and negative below it; the fp32 evaluation is off by at most
+//     noise(j) <= 2^-24 (j|z_j| + 2|S_j| + 1) <= 2^-24 (3 j |z_j| + 1)      (all z <= 0)
+// so the outcome at a rank is only open when |f(j)| is inside that noise.  The search therefore
+// works on tie groups (value v, t elements, m elements above with fp64 sum S; f = 1 + m v - S for
+// every rank of the group):
+//   * f >  B(m, t, v) = 2^-23 (3 (m + t)|v| + 1): the group and everything above pass   (robust)
+//   * f < -B: the group fails;   f(next group) < -2^-23 (3 N |v_next| + 1), N = elements the
+//     search can see: every deeper rank fails                                            (robust)
+//   * otherwise the group's t ranks are evaluated one by one with exactly the oracle's fp32
+//     expressions (spread over the lanes that hold the row) and the passing ones counted.
+// The walk goes up from Michelot's fixed point to the first robust-pass group, then down through
+// the undecided groups; the count of passing ranks and the prefix sum at that count are the
+// oracle's s and S_s bit for bit -- including rows where hundreds or thousands of elements tie at
+// or within an ulp of the threshold and the oracle's test passes at isolated ranks.
+
 // The oracle's test at rank j = m_gt + r inside the tie group of value v (r = 1..t), given the
 // count m_gt and fp64 sum S_gt of the elements strictly above v:
 //     (float)j * v  >  (float)(S_gt + r*v) - 1.0f
@@ -171,26 +195,43 @@ __device__ __forceinline__ bool cond_rank(int m_gt, double S_gt, float v, int r)
     return j * v > c;
 }
 
-// rank 1 of the tie group below (m, S) fails the test, but by no more than rounding noise
-__device__ __forceinline__ bool near_rank(int m, double S_m, float v)
+// +1: every rank of the group (and of every group above) passes; -1: every rank of the group
+// fails; 0: inside the rounding noise of the fp32 test, count rank by rank
+__device__ __forceinline__ int classify_group(int m_gt, double S_gt, float v, int t)
 {
-    const float jv = (float)(m + 1) * v;
-    const float Sf = (float)(S_m + (double)v);
-    const float c = Sf - 1.0f;
-    const float scale = fmaxf(fmaxf(fabsf(jv), fabsf(Sf)), 1.0f);
-    return c - jv <= 1e-6f * scale;
+    const double d = (double)m_gt * (double)v - S_gt + 1.0;
+    const double B = 0x1p-23 * (3.0 * (double)(m_gt + t) * fabs((double)v) + 1.0);
+    return d > B ? 1 : (d < -B ? -1 : 0);
 }
 
-constexpr int kTieExact = 64;
+// every rank below (m, S), whose largest value is vnext, fails robustly (nvis >= ranks in sight)
+__device__ __forceinline__ bool deeper_all_fail(int m, double S_m, float vnext, int nvis)
+{
+    const double d = (double)m * (double)vnext - S_m + 1.0;
+    return d < -0x1p-23 * (3.0 * (double)nvis * fabs((double)vnext) + 1.0);
+}
 
-// Number of ranks r = 1..t of a tie group whose test holds.  Rare (ties exactly at the edge), so it
-// is kept out of line: inlined three times it cost the small-row kernels their register budget.
-__device__ __noinline__ int count_ranks(int m_gt, double S_gt, float v, int t)
+// This thread's share of the ranks r = 1..t of a tie group whose test holds (r = first + 1,
+// first + 1 + stride, ...).  Rare (ties inside the rounding noise of the edge), so it is kept out
+// of line: inlined it cost the small-row kernels their register budget.
+__device__ __noinline__ int count_ranks_part(int m_gt, double S_gt, float v, int t, int first,
+                                             int stride)
 {
     int n = 0;
-    for (int r = 1; r <= t; ++r) n += cond_rank(m_gt, S_gt, v, r) ? 1 : 0;
+    for (int r = first + 1; r <= t; r += stride) n += cond_rank(m_gt, S_gt, v, r) ? 1 : 0;
     return n;
-}   // tie groups at the edge up to this size are counted rank by rank
+}
+
+// Elements at or below this value (max-shifted frame) can neither be in the support (tau >= -1)
+// nor pass the oracle's fp32 test by rounding: for z_j = -u, f(j) <= s (|tau| - u) <= 1 - u, and
+// 1 - u < -2^-24 (3 K u + 1) once u > (1 + 2^-23) / (1 - 3 K 2^-23).  Candidate lists keep what is
+// above it (K <= 2^20; wider rows run the search on the whole row).
+constexpr int kCandMaxK = 1 << 20;
+__device__ __forceinline__ float cand_floor(int K)
+{
+    const float a = 3.0f * (float)K * 0x1p-23f;
+    return -((1.0f + 0x1p-23f) / (1.0f - a)) * (1.0f + 1e-5f);
+}
 
 struct Edge {
     int m_gt, t;
@@ -198,24 +239,37 @@ struct Edge {
     float vnext;
 };
 
-template <int E, class Red>
-__device__ __forceinline__ Edge edge_pass(const float (&z)[E], float lo, Red& red)
+// A source hands every element of the row (max-shifted) to f, in a fixed per-thread order.
+template <int E>
+struct RegSrc {
+    const float (&z)[E];
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) const
+    {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            float v = z[e];
+            // opaque copy: stops LICM from hoisting 64 float->double conversions (128 VGPRs) out of
+            // the edge loop, and the compare masks of one pass from staying alive into the next
+            asm volatile("" : "+v"(v));
+            f(v);
+        }
+    }
+};
+
+template <class Src, class Red>
+__device__ __forceinline__ Edge edge_pass(const Src& src, float lo, Red& red)
 {
     int mg = 0, t = 0;
     double S = 0.0;
     float vn = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        float v = z[e];
-        // opaque copy: stops LICM from hoisting 64 float->double conversions (128 VGPRs) out of
-        // the caller's edge loop
-        asm volatile("" : "+v"(v));
-        bool gt = v > lo;
+    src.each([&](float v) {
+        const bool gt = v > lo;
         mg += gt ? 1 : 0;
         t += (v == lo) ? 1 : 0;
         S += gt ? (double)v : 0.0;
         vn = (v < lo) ? fmaxf(vn, v) : vn;
-    }
+    });
     red.edge(mg, t, S, vn);
     Edge r;
     r.m_gt = mg;
@@ -225,11 +279,79 @@ __device__ __forceinline__ Edge edge_pass(const float (&z)[E], float lo, Red& re
     return r;
 }
 
-// Threshold search on max-shifted values v[] (padding = -inf; every element that can be in the
-// support, i.e. > -1, must be present): Michelot iteration, then the exact edge.  Returns the
-// oracle's support size s and the fp64 sum S of its s largest elements.
+// The exact edge from a lower bound tau of the threshold that is at (or within rounding of)
+// Michelot's fixed point.  nvis: upper bound of the number of elements src shows.  Returns the
+// oracle's support size s and the fp64 sum S of the s largest elements.  Every decision below comes
+// out of `red`, so control flow is uniform over the lanes that hold the row.
+template <class Src, class Red>
+__device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, int nvis, int& s_out,
+                                           double& S_out)
+{
+    float lo = INFINITY;
+    src.each([&](float v) { lo = (v > tau) ? fminf(lo, v) : lo; });
+    lo = red.min(lo);
+
+    // up to the first group that passes robustly (the top group always does: f = 1)
+    Edge b;
+    for (;;) {
+        b = edge_pass(src, lo, red);
+        if (b.m_gt == 0 || classify_group(b.m_gt, b.S_gt, lo, b.t) > 0) break;
+        float up = INFINITY;
+        src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
+        lo = red.min(up);
+    }
+    const int m_top = b.m_gt + b.t;
+    const double S_top = b.S_gt + (double)b.t * (double)lo;
+
+    // down through the groups the noise bound cannot decide
+    int m = m_top, C = 0;
+    double S = S_top, S_at = S_top;
+    float vnext = b.vnext;
+    const float first_lo = vnext;
+    bool open = true, dirty = false;   // open: the passing ranks so far are a prefix of the ranks
+    while (vnext > -INFINITY) {
+        if (deeper_all_fail(m, S, vnext, nvis)) break;
+        const Edge g = edge_pass(src, vnext, red);
+        const int k = classify_group(g.m_gt, g.S_gt, vnext, g.t);
+        int cnt = k > 0 ? g.t : 0;
+        if (k == 0)
+            cnt = red.sum(count_ranks_part(g.m_gt, g.S_gt, vnext, g.t, red.idx(), red.stride()));
+        if (open) {
+            S_at = g.S_gt + (double)cnt * (double)vnext;
+            open = cnt == g.t;
+        } else if (cnt > 0) {
+            dirty = true;
+        }
+        C += cnt;
+        m = g.m_gt + g.t;
+        S = g.S_gt + (double)g.t * (double)vnext;
+        vnext = g.vnext;
+    }
+    int s = m_top + C;
+    if (dirty) {
+        // ranks passed below a rank that failed: the prefix sum at the count s is read off a second
+        // walk over the same groups (needs two undecided groups in a row: practically never)
+        int rem = C;
+        float lo2 = first_lo;
+        for (;;) {
+            const Edge g = edge_pass(src, lo2, red);
+            const int take = rem < g.t ? rem : g.t;
+            S_at = g.S_gt + (double)take * (double)lo2;
+            rem -= take;
+            if (rem <= 0 || !(g.vnext > -INFINITY)) break;
+            lo2 = g.vnext;
+        }
+    }
+    if (s < 1) { s = 1; S_at = 0.0; }   // rows without a finite maximum (inf / NaN input)
+    s_out = s;
+    S_out = S_at;
+}
+
+// Threshold search on max-shifted values v[] (padding = -inf; every element above cand_floor(K)
+// must be present): Michelot iteration, then the exact edge.
 template <int E, class Red>
-__device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int& s_out, double& S_out)
+__device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int nvis, int& s_out,
+                                           double& S_out)
 {
     // --- Michelot iteration from the lower bound tau >= -1 (z_max = 0 after the shift).
     float tau = -1.0f;
@@ -248,83 +370,11 @@ __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int& s
         cnt_prev = c;
         tau = fmaxf(tau, (s - 1.0f) / (float)c);
     }
-
-    // --- exact edge: candidate set {z > tau} = {z >= lo}, lo = its smallest value.
     // (tau is laundered so the compiler recomputes these compares instead of keeping the last
     // iteration's 64 lane masks alive in SGPRs across the reductions)
     asm volatile("" : "+v"(tau));
-    float lo = INFINITY;
-#pragma unroll
-    for (int e = 0; e < E; ++e) lo = (z[e] > tau) ? fminf(lo, z[e]) : lo;
-    lo = red.min(lo);
-
-    int s_final;
-    double S_final;
-    int dir = 0;
-    bool probe = false;
-    for (;;) {
-        Edge b = edge_pass(z, lo, red);
-        if (probe) {   // b = the tie group just below a support that is otherwise settled
-            int cnt = 0;
-            if (b.t > 1 && b.t <= kTieExact) cnt = count_ranks(b.m_gt, b.S_gt, lo, b.t);
-            s_final = b.m_gt + cnt;
-            S_final = b.S_gt + (double)cnt * (double)lo;
-            break;
-        }
-        int rstar;
-        if (b.t > 1 && b.t <= kTieExact) {
-            // the oracle's support size is the NUMBER of ranks whose test holds; inside a small tie
-            // group at the edge rounding can make that pattern non-monotone (fail, pass), so count
-            rstar = count_ranks(b.m_gt, b.S_gt, lo, b.t);
-        } else if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
-            rstar = b.t;
-        } else if (b.t == 1 || !cond_rank(b.m_gt, b.S_gt, lo, 1)) {
-            rstar = 0;
-        } else {  // edge inside a tie group (rounding only): largest r whose test holds
-            int a = 1, hi = b.t;
-            while (hi - a > 1) {
-                int mid = (a + hi) >> 1;
-                if (cond_rank(b.m_gt, b.S_gt, lo, mid)) a = mid; else hi = mid;
-            }
-            rstar = a;
-        }
-        if (rstar == b.t) {
-            int m = b.m_gt + b.t;
-            double S_m = b.S_gt + (double)b.t * (double)lo;
-            if (dir >= 0 && b.vnext > -INFINITY) {
-                if (cond_rank(m, S_m, b.vnext, 1)) {
-                    dir = 1;  // the next group still passes the test: grow
-                    lo = b.vnext;
-                    continue;
-                }
-                // In exact arithmetic every rank of a tie group passes or fails together; if rank 1
-                // of the next group failed only by rounding, later ranks of that group may pass,
-                // and the oracle counts them: look at that group once (rare).
-                if (!probe && near_rank(m, S_m, b.vnext)) {
-                    probe = true;
-                    lo = b.vnext;
-                    continue;
-                }
-            }
-            s_final = m;
-            S_final = S_m;
-            break;
-        }
-        if (rstar > 0 || dir > 0 || b.m_gt == 0) {
-            s_final = b.m_gt + rstar;
-            S_final = b.S_gt + (double)rstar * (double)lo;
-            if (s_final == 0) { s_final = b.t; S_final = (double)b.t * (double)lo; }  // unreachable for finite rows
-            break;
-        }
-        // the whole group fails: shrink to the next larger value
-        dir = -1;
-        float up = INFINITY;
-#pragma unroll
-        for (int e = 0; e < E; ++e) up = (z[e] > lo) ? fminf(up, z[e]) : up;
-        lo = red.min(up);
-    }
-    s_out = s_final;
-    S_out = S_final;
+    const RegSrc<E> src{z};
+    solve_edge(src, red, tau, nvis, s_out, S_out);
 }
 
 // ------------------------------------------------------------------------------- candidates
@@ -405,13 +455,17 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
 
 // Rows with more than kCandCap elements within 1 of the maximum (narrow logit distributions): a
 // few full-width Michelot steps raise the bound tau_k <= tau first, and the candidates are taken
-// above tau_k - kLazyMargin instead.  The fp32 sums behind tau_k are off by far less than the
-// margin (<= 70 roundings of 2^-24 each on values in [-1, 0]), and the oracle's own fp32 test
-// cannot admit an element more than ~1e-6 below tau, so the list still holds the whole support
-// and the elements its edge test can look at.
+// above tau_k - lazy_margin(K) instead.  The fp32 sums behind tau_k are off by far less than the
+// margin (<= 70 roundings of 2^-24 each on values in [-1, 0]), and by the argument at cand_floor
+// (with tau_k in place of -1) an element further below tau_k than (3 K + 1) 2^-23 / (1 - 3 K 2^-23)
+// cannot pass the oracle's fp32 test even by rounding, so the list still holds the whole support
+// and every element the exact edge has to look at.
 constexpr int kLazyPasses = 8;
 constexpr int kLazyTry = 2 * kCandCap;      // attempt the compaction once |{z > tau_k}| is below this
-constexpr float kLazyMargin = 1e-3f;
+__device__ __forceinline__ float lazy_margin(float floor_k)
+{
+    return fmaxf(1e-3f, (-floor_k - 1.0f) + 1e-5f);
+}
 
 // The threshold of any SUBSET of a row is a lower bound of the row's threshold (more elements can
 // only raise tau).  One value per lane -- the lane's own maximum -- through a wave-local Michelot
@@ -438,7 +492,7 @@ __device__ __forceinline__ float subset_bound(float v)
 // are the candidates above tau.  One lane group of G lanes per row.  The lane that fills slot 0
 // is also the one that overwrites it with the overflow mark (same thread, program order).
 template <int Q, int G>
-__device__ __forceinline__ void emit_cols_from_candidates(const float (&c)[Q], const int (&cc)[Q],
+__device__ __forceinline__ int emit_cols_from_candidates(const float (&c)[Q], const int (&cc)[Q],
                                                           float tau, int gl, int grp,
                                                           int32_t* __restrict__ list, int cap, bool live,
                                                           int mark = kColsOverflow)
@@ -461,6 +515,7 @@ __device__ __forceinline__ void emit_cols_from_candidates(const float (&c)[Q], c
         if (base > cap) { if (wrote0) list[0] = mark; }
         else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
     }
+    return base;   // #{p > 0} of the row (the mark and the support mask are decided on this count)
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -476,12 +531,16 @@ __device__ __forceinline__ void wave_lds_sync()
 // cand: LDS, NW == 1: 2*kCandCap words private to this wave (values, columns); NW > 1: NW*64
 // floats + NW ints + NW*64 ints (values, counts, columns).
 // list != null: the row's support list is wanted; returns true if it was written
-// here (from the candidates), false if the caller has to scan the registers.
+// here (from the candidates; n_listed = the #{p > 0} it saw), false if the caller has to scan the
+// registers.
 template <int E, int NW, bool CAND, bool VEC, class Red>
-__device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int& supp,
-                                              float& tau_out, int32_t* list = nullptr, int cap = 0,
+__device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int K, int& supp,
+                                              float& tau_out, int& n_listed,
+                                              int32_t* list = nullptr, int cap = 0,
                                               bool live = true, int mark = kColsOverflow)
 {
+    const float floor_k = cand_floor(K);
+    const float margin = lazy_margin(floor_k);
     float mx = z[0];
 #pragma unroll
     for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
@@ -494,19 +553,19 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
     int s_final = 1;
     double S_final = 0.0;
     bool fast = false;
-    if constexpr (CAND) {
+    if constexpr (CAND) {   // K <= 65536 < kCandMaxK in every kernel that comes through here
         const int lane = threadIdx.x & 63;
         float c[kCandPerLane];
         int cc[kCandPerLane];
         if constexpr (NW == 1) {
             int* ccols = list ? reinterpret_cast<int*>(cand + kCandCap) : nullptr;
             const int colbase = VEC ? lane * 4 : lane, colstep = VEC ? 256 : 64;
-            int n_c = compact_candidates<E, VEC>(z, -1.0f, cand, kCandCap, ccols, colbase, colstep);
+            int n_c = compact_candidates<E, VEC>(z, floor_k, cand, kCandCap, ccols, colbase, colstep);
             if (n_c > kCandCap) {
                 float tau = subset_bound(lane_mx);
                 wave_lds_sync();
-                n_c = compact_candidates<E, VEC>(z, tau - kLazyMargin, cand, kCandCap, ccols, colbase,
-                                                 colstep);
+                n_c = compact_candidates<E, VEC>(z, fmaxf(tau - margin, floor_k), cand, kCandCap, ccols,
+                                                 colbase, colstep);
                 int cnt_prev = 0x7fffffff;
                 for (int pass = 0; n_c > kCandCap && pass < kLazyPasses; ++pass) {
                     int cn = 0;
@@ -523,8 +582,8 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
                     if (cn <= kLazyTry) {
                         wave_lds_sync();
-                        n_c = compact_candidates<E, VEC>(z, tau - kLazyMargin, cand, kCandCap, ccols,
-                                                         colbase, colstep);
+                        n_c = compact_candidates<E, VEC>(z, fmaxf(tau - margin, floor_k), cand, kCandCap,
+                                                         ccols, colbase, colstep);
                         if (n_c <= kCandCap) break;
                     }
                 }
@@ -544,9 +603,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             const int wave = threadIdx.x >> 6;
             int* cnt = reinterpret_cast<int*>(cand + NW * 64);
             int* ccols = list ? cnt + NW : nullptr;   // NW*64 candidate columns after the counts
-            // candidates above thr = -1 first; if they do not fit (narrow logit distribution),
+            // candidates above the floor first; if they do not fit (narrow logit distribution),
             // block-wide Michelot steps raise the bound and the compaction is tried again above it
-            float thr = -1.0f, tau = -1.0f;
+            float thr = floor_k, tau = -1.0f;
+            bool first = true;
             int cnt_prev = 0x7fffffff, passes = 0;
             for (;;) {
                 const int n_w = compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
@@ -584,7 +644,8 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 }
                 __syncthreads();  // the lists are rewritten by the next attempt / the next row
                 if (fast) break;
-                if (thr == -1.0f) {   // first failure: the best wave-local subset bound, then retry
+                if (first) {   // first failure: the best wave-local subset bound, then retry
+                    first = false;
                     tau = red.max(subset_bound(lane_mx));
                     // ... refined on the subset of all 64 NW lane maxima (one value per lane: block
                     // reductions, but no pass over the registers)
@@ -597,7 +658,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                         cp = cn;
                         tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
                     }
-                    thr = tau - kLazyMargin;
+                    thr = fmaxf(tau - margin, floor_k);
                     continue;
                 }
                 bool give_up = false;
@@ -617,20 +678,20 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     if (cn <= kLazyTry) break;
                 }
                 if (give_up) break;
-                thr = tau - kLazyMargin;
+                thr = fmaxf(tau - margin, floor_k);
             }
         }
         if (fast) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers
-            solve_core(c, wred, s_final, S_final);
+            solve_core(c, wred, kCandCap, s_final, S_final);
             if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-                emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,
-                                                            live && (NW == 1 || threadIdx.x < 64), mark);
+                n_listed = emit_cols_from_candidates<kCandPerLane, 64>(
+                    c, cc, tau_c, lane, 0, list, cap, live && (NW == 1 || threadIdx.x < 64), mark);
             }
         }
     }
-    if (!fast) solve_core(z, red, s_final, S_final);
+    if (!fast) solve_core(z, red, K, s_final, S_final);
 
     float c_s = (float)S_final - 1.0f;
     float tau_f = c_s / (float)s_final;
@@ -647,11 +708,12 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
 // instead of E.  If any row of the wave has more candidates than its slice holds, the whole wave
 // takes the full-width search.
 template <int E, int G, bool VEC>
-__device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand,
+__device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand, int K,
                                                     int& supp, float& tau_out,
                                                     int32_t* list = nullptr, int cap = 0,
                                                     bool live = true)
 {
+    const float floor_k = cand_floor(K);
     static_assert(G < 64, "lane groups inside one wave");
     constexpr int Q = (G >= 16) ? 2 : 32 / G;   // candidates per lane: capacity G*Q = 32, 32, 64
     constexpr int CAP = G * Q;
@@ -670,7 +732,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     int base = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const bool in = z[e] > -1.0f;
+        const bool in = z[e] > floor_k;
         const unsigned long long m = __ballot(in);
         if (m != 0ull) {  // wave-uniform
             const unsigned mine = (unsigned)(m >> (grp * G)) & group_bits;
@@ -696,14 +758,14 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             cc[q] = (have && list) ? ccols[gl + G * q] : 0;
         }
         wave_lds_sync();
-        solve_core(c, red, s_final, S_final);
+        solve_core(c, red, CAP, s_final, S_final);
         if (list) {
             const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
             emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live);
             listed = true;
         }
     } else {
-        solve_core(z, red, s_final, S_final);
+        solve_core(z, red, K, s_final, S_final);
     }
     const float c_s = (float)S_final - 1.0f;
     const float tau_f = c_s / (float)s_final;
@@ -896,7 +958,7 @@ __device__ __forceinline__ void bwd_row_gather_bits(const float* __restrict__ dy
 // Register scan (rows that took the full-width threshold search): one pass; the lane that fills
 // slot 0 overwrites it with the overflow mark if the row has more than cap non-zeros.
 template <int E, int G, bool VEC>
-__device__ __forceinline__ void emit_support_cols(const float (&p)[E], int gl, int grp,
+__device__ __forceinline__ int emit_support_cols(const float (&p)[E], int gl, int grp,
                                                   int32_t* __restrict__ list, int cap, bool live,
                                                   int mark = kColsOverflow)
 {
@@ -918,6 +980,7 @@ __device__ __forceinline__ void emit_support_cols(const float (&p)[E], int gl, i
         if (base > cap) { if (wrote0) list[0] = mark; }
         else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
     }
+    return base;
 }
 
 // dx of a row from its support list, in two rounds of stores: the whole row as zeros (no
@@ -1066,17 +1129,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void spar
     float t, h = 0.0f;
     int32_t* list = cols ? cols + row * cap : nullptr;
     bool listed;
+    int n_listed = 0;   // #{p > 0} as counted by whoever wrote (or gave up on) the row's list
     if constexpr (GCAND)
-        listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, s, t,
+        listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, K, s, t,
                                                 list, cap, live);
     else
         listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
-                                                s, t, list, cap, live, mark);
+                                                K, s, t, n_listed, list, cap, live, mark);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
-    if (cols && !listed) emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark);
+    if (cols && !listed) n_listed = emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark);
     if constexpr (MASKS) {
-        // more than cap non-zeros (s is wave-uniform here): leave the pattern as one bit per register
-        if (cols && mask && s > cap && live) {
+        // The row was marked kColsMask exactly when that count exceeded cap (wave-uniform here; NOT
+        // supp_size, which counts passing ranks and can differ from #{p > 0} with ties at the
+        // threshold): leave the pattern as one bit per register
+        if (cols && mask && n_listed > cap && live) {
             uint32_t mlo = 0u, mhi = 0u;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1112,9 +1178,9 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_fwd_block_kernel(
         float z[E];
         load_row<E, VEC, FULL, true>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
-        int s, n = 0;
+        int s, n = 0, n_listed = 0;
         float t, h = 0.0f;
-        const bool listed = sparsemax_row<E, NW, true, VEC>(z, red, cand, s, t,
+        const bool listed = sparsemax_row<E, NW, true, VEC>(z, red, cand, K, s, t, n_listed,
                                                             cols ? cols + row * cap : nullptr, cap, true);
         if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
         store_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, z);
@@ -1343,7 +1409,7 @@ struct RowStream {
 
 // solve_core with the row behind a RowStream (same decisions, every pass re-reads the row)
 template <class Src, class Red>
-__device__ void solve_stream(const Src& src, Red& red, float tau, int& s_out, double& S_out)
+__device__ void solve_stream(const Src& src, Red& red, float tau, int nvis, int& s_out, double& S_out)
 {
     int cnt_prev = 0x7fffffff;
     for (;;) {
@@ -1355,75 +1421,7 @@ __device__ void solve_stream(const Src& src, Red& red, float tau, int& s_out, do
         cnt_prev = c;
         tau = fmaxf(tau, (sm - 1.0f) / (float)c);
     }
-    float lo = INFINITY;
-    src.each([&](float v) { lo = (v > tau) ? fminf(lo, v) : lo; });
-    lo = red.min(lo);
-    int s_final;
-    double S_final;
-    int dir = 0;
-    bool probe = false;
-    for (;;) {
-        Edge b;
-        {
-            int mg = 0, t = 0;
-            double S = 0.0;
-            float vn = -INFINITY;
-            src.each([&](float v) {
-                const bool gt = v > lo;
-                mg += gt ? 1 : 0;
-                t += (v == lo) ? 1 : 0;
-                S += gt ? (double)v : 0.0;
-                vn = (v < lo) ? fmaxf(vn, v) : vn;
-            });
-            red.edge(mg, t, S, vn);
-            b.m_gt = mg; b.t = t; b.S_gt = S; b.vnext = vn;
-        }
-        if (probe) {
-            int cnt = 0;
-            if (b.t > 1 && b.t <= kTieExact) cnt = count_ranks(b.m_gt, b.S_gt, lo, b.t);
-            s_final = b.m_gt + cnt;
-            S_final = b.S_gt + (double)cnt * (double)lo;
-            break;
-        }
-        int rstar;
-        if (b.t > 1 && b.t <= kTieExact) {
-            rstar = count_ranks(b.m_gt, b.S_gt, lo, b.t);
-        } else if (cond_rank(b.m_gt, b.S_gt, lo, b.t)) {
-            rstar = b.t;
-        } else if (b.t == 1 || !cond_rank(b.m_gt, b.S_gt, lo, 1)) {
-            rstar = 0;
-        } else {
-            int a = 1, hi = b.t;
-            while (hi - a > 1) {
-                int mid = (a + hi) >> 1;
-                if (cond_rank(b.m_gt, b.S_gt, lo, mid)) a = mid; else hi = mid;
-            }
-            rstar = a;
-        }
-        if (rstar == b.t) {
-            int m = b.m_gt + b.t;
-            double S_m = b.S_gt + (double)b.t * (double)lo;
-            if (dir >= 0 && b.vnext > -INFINITY) {
-                if (cond_rank(m, S_m, b.vnext, 1)) { dir = 1; lo = b.vnext; continue; }
-                if (near_rank(m, S_m, b.vnext)) { probe = true; lo = b.vnext; continue; }
-            }
-            s_final = m;
-            S_final = S_m;
-            break;
-        }
-        if (rstar > 0 || dir > 0 || b.m_gt == 0) {
-            s_final = b.m_gt + rstar;
-            S_final = b.S_gt + (double)rstar * (double)lo;
-            if (s_final == 0) { s_final = b.t; S_final = (double)b.t * (double)lo; }
-            break;
-        }
-        dir = -1;
-        float up = INFINITY;
-        src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
-        lo = red.min(up);
-    }
-    s_out = s_final;
-    S_out = S_final;
+    solve_edge(src, red, tau, nvis, s_out, S_out);
 }
 
 template <bool VEC, bool EXTRA>
@@ -1461,12 +1459,15 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
             cp = cn;
             tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
         }
-        float thr = fmaxf(tau - kLazyMargin, -1.0f);
+        const float floor_k = cand_floor(K < kCandMaxK ? K : kCandMaxK);
+        const float margin = lazy_margin(floor_k);
+        float thr = fmaxf(tau - margin, floor_k);
         float c[kCandPerLane];
         int cc[kCandPerLane];
         bool fast = false;
         int cnt_prev = 0x7fffffff, passes = 0;
         for (;;) {
+            if (K > kCandMaxK) break;   // beyond the candidate floor's range: search the whole row
             int base = 0;
             for (int i0 = 0; i0 < nstep; i0 += NT) {   // block-uniform trip count
                 const int i = i0 + threadIdx.x;
@@ -1536,21 +1537,21 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
                 if (cn <= kLazyTry) break;
             }
             if (give_up) break;
-            thr = tau - kLazyMargin;
+            thr = fmaxf(tau - margin, floor_k);
         }
         int s_final = 1;
         double S_final = 0.0;
         int32_t* list = cols ? cols + row * cap : nullptr;
         if (fast) {
             WaveRed<64> wred;
-            solve_core(c, wred, s_final, S_final);
+            solve_core(c, wred, kCandCap, s_final, S_final);
             if (list) {
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
                 emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,
                                                             threadIdx.x < 64);
             }
         } else {
-            solve_stream(src, red, tau, s_final, S_final);
+            solve_stream(src, red, tau, K, s_final, S_final);
             if (list && threadIdx.x == 0) list[0] = kColsOverflow;
         }
         const float tau_f = ((float)S_final - 1.0f) / (float)s_final;

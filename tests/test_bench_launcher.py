@@ -1,0 +1,53 @@
+"""CPU: `python bench.py --gpus N` (N > 1, no launcher environment) becomes the parent of an N-rank
+torch.distributed.run child; the parent touches no GPU, relays rank 0's line and fails when the
+child fails."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_child_command_is_the_drivers_launch_line():
+    import bench
+    cmd = bench.child_command(8, ["--gpus", "8", "--steps", "3", "--warmup", "1"], 29511)
+    assert cmd[0] == sys.executable
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_parent_refuses_more_ranks_than_gpus_without_touching_one():
+    # no GPU in the build container: the parent must stop at the device count (exit 2), before any
+    # HIP call, and print no JSON line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return   # a real multi-GPU box runs the bench; covered by the driver
+    assert res.returncode == 2, (res.returncode, res.stderr[-500:])
+    assert "visible" in res.stderr and not res.stdout.strip()
+
+
+def test_parent_relays_the_line_and_the_exit_code(tmp_path, monkeypatch):
+    import bench
+    fake = tmp_path / "fake_child.py"
+    fake.write_text("import json, sys\n"
+                    "print('noise from a rank')\n"
+                    "print(json.dumps({'metric': 'm', 'n_gpus': int(sys.argv[1]), 'value': 1.0}))\n"
+                    "sys.exit(int(sys.argv[2]))\n")
+
+    class A:
+        gpus = 2
+
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    for code, n, expect in ((0, 2, 0), (3, 2, 3), (0, 1, 1)):
+        monkeypatch.setattr(bench, "child_command",
+                            lambda g, argv, port, c=code, n=n: [sys.executable, str(fake), str(n), str(c)])
+        assert bench.launch_ranks(A(), []) == expect

@@ -223,9 +223,7 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     get clusters planted around the oracle's threshold -- hundreds of elements inside the margin, a
     pair 1 ulp below tau, a pair of exact ties at tau -- and p, supp, tau and the support lists
     must still equal the oracle's bit for bit; the widest cases (support > 256) fall through to the
-    full-width search.  (Hundreds of exact ties AT tau are the documented exception: there the
-    oracle's own fp32 test passes at isolated ranks deep inside the tie group by rounding, and its
-    count-of-passing-ranks support size is not a prefix any more.)"""
+    full-width search.  (Hundreds to thousands of exact ties AT tau: test_tie_groups_at_threshold.)"""
     from lvmhelpers import _native
     R = 256 if K <= 4096 else 48
     rng = np.random.default_rng(int(1e4 * sigma) + K)
@@ -269,6 +267,130 @@ def test_narrow_rows_lazy_candidates(dev, oracle_mod, K, sigma):
     # without the lists (different kernel instantiation of the same search)
     p2, supp2, _, _, _ = _native.sparsemax_fwd(xt)
     assert np.array_equal(p2.cpu().numpy(), p_ref) and np.array_equal(supp2.cpu().numpy(), s_ref)
+
+
+def _tie_rows(rng, K, oracle_mod):
+    """Rows whose oracle threshold sits inside / next to big groups of tied values: there the
+    oracle's fp32 rank test is decided by rounding, passes at isolated ranks, and its support size
+    (the COUNT of passing ranks) is not the size of a prefix.  One row per construction."""
+    f32 = np.float32
+    rows = []
+
+    def base(sig):
+        x = (sig * rng.standard_normal(K)).astype(f32)
+        _, _, tau0, _ = oracle_mod.sparsemax_fwd(x[None])
+        t = f32(tau0[0] + x.max())
+        below = np.flatnonzero(x < t)
+        rng.shuffle(below)
+        return x, t, below
+
+    for sig in (1.0, 0.05):
+        for n in (300, K // 4, K - 64):
+            for mode in range(5):
+                x, t, below = base(sig)
+                idx = below[:min(n, below.size)]
+                if mode == 0:
+                    x[idx] = t                                       # ties exactly at tau
+                elif mode == 1:
+                    x[idx] = np.nextafter(t, f32(-np.inf))           # 1 ulp below
+                elif mode == 2:
+                    x[idx] = np.nextafter(t, f32(np.inf))            # 1 ulp above
+                elif mode == 3:                                      # three groups an ulp apart
+                    h = idx.size // 3
+                    x[idx[:h]] = t
+                    x[idx[h:2 * h]] = np.nextafter(t, f32(-np.inf))
+                    x[idx[2 * h:]] = np.nextafter(t, f32(np.inf))
+                else:
+                    x[idx] = t - f32(1e-5)                           # a crowd 1e-5 below tau
+                rows.append(x)
+    for eps in (0.0, 1e-6, -1e-6, 2e-3, -2e-3, 1e-4, 2e-2, 1e-5, -1e-5):
+        x = np.zeros(K, f32)                                         # one spike, K-1 ties at spike-1-eps
+        x[7 % K] = f32(1.0 + eps)
+        rows.append(x)
+    for a in (2, 100, K // 2):
+        for d in (1.0 / a, 1.0 / a + 1e-6, 1.0 / a - 1e-6):
+            x = np.full(K, f32(-d), f32)                             # a at 0, K-a at the a-element tau
+            x[:a] = 0.0
+            rows.append(x)
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("K", [256, 1000, 4096, 65536, 131072])
+def test_tie_groups_at_threshold(dev, oracle_mod, K):
+    """Hundreds to 131k elements tied exactly at, one ulp around, or 1e-5 below the threshold: supp
+    (the oracle's count of passing ranks, even where they are not a prefix), tau, p and the lists
+    must equal the oracle's bit for bit, with and without the support lists, and the backward that
+    divides by that supp must agree."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(K)
+    x = _tie_rows(rng, K, oracle_mod)
+    R = x.shape[0]
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    assert np.any(s_ref != nnz_ref)          # the construction does split tie groups
+    xt = torch.from_numpy(x).to(dev)
+    p, supp, nnz, tau, _, cols, mask = _native.sparsemax_fwd(xt, want_nnz=True, want_tau=True,
+                                                             want_cols=True, want_mask=True)
+    bad = np.flatnonzero(supp.cpu().numpy() != s_ref)
+    assert bad.size == 0, (bad[:8], supp.cpu().numpy()[bad[:8]], s_ref[bad[:8]])
+    assert np.array_equal(tau.cpu().numpy(), tau_ref)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    assert np.array_equal(nnz.cpu().numpy(), nnz_ref)
+    p2, supp2, _, _, _ = _native.sparsemax_fwd(xt)
+    assert np.array_equal(p2.cpu().numpy(), p_ref) and np.array_equal(supp2.cpu().numpy(), s_ref)
+    c = cols.cpu().numpy()
+    cap = c.shape[1]
+    for r in range(R):
+        nz = np.flatnonzero(p_ref[r] > 0)
+        if c[r, 0] >= -1:
+            assert sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
+        elif K <= 4096:
+            assert nz.size > cap
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    dyt = torch.from_numpy(dy).to(dev)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    for dxt in (_native.sparsemax_bwd_cols(dyt, cols, p, supp, mask), _native.sparsemax_bwd(dyt, p, supp)):
+        assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 2e-6 * scale)
+
+
+def test_mask_mark_follows_the_nonzero_count(dev, oracle_mod):
+    """A row is marked -3 (support mask) exactly when #{p > 0} exceeds the list capacity; the
+    oracle's supp_size can be smaller than that count when a tie group straddles the threshold
+    (supp <= cap < nnz), and the mask must have been written for such a row: the masked backward
+    has to equal the p-based one."""
+    from lvmhelpers import _native
+    f32 = np.float32
+    K, cap = 4096, _native.SUPPORT_COLS_CAP
+    rng = np.random.default_rng(5)
+    rows = []
+    # a support of m distinct values + a tie group of t values placed so that the group's common
+    # value is a hair above the threshold of (m + some of the group): search for supp <= cap < nnz
+    for trial in range(4000):
+        m = int(rng.integers(1, cap))
+        t = int(rng.integers(cap - m + 1, 3 * cap))
+        top = np.sort(rng.uniform(-0.5, 0.0, m)).astype(f32)[::-1].copy()
+        top[0] = 0.0
+        v = f32((top.astype(np.float64).sum() - 1.0) / m) + f32(rng.choice([0.0, 1e-7, -1e-7, 3e-8]))
+        x = np.full(K, f32(-5.0), f32)
+        x[:m] = top
+        x[m:m + t] = v
+        _, s1, _, n1 = oracle_mod.sparsemax_fwd(x[None])
+        if s1[0] <= cap < n1[0]:
+            rows.append(rng.permutation(x))
+            if len(rows) >= 8:
+                break
+    assert rows, "no supp <= cap < nnz row found"
+    x = np.stack(rows)
+    p_ref, s_ref, _, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    xt = torch.from_numpy(x).to(dev)
+    dyt = torch.randn(x.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
+    assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(supp.cpu().numpy(), s_ref)
+    assert np.all(cols[:, 0].cpu().numpy() == -3)
+    mask_garbage = torch.full_like(mask, -1)          # the same rows with an unwritten mask would gather junk
+    dx = _native.sparsemax_bwd_cols(dyt, cols, p, supp, mask)
+    assert torch.equal(dx, _native.sparsemax_bwd(dyt, p, supp))
+    del mask_garbage
 
 
 @pytest.mark.parametrize("R,K", [(6, 5000), (5, 8192), (4, 50001), (7, 4097), (9, 3001), (64, 255)])
