@@ -229,6 +229,9 @@ __device__ __noinline__ int count_ranks_part(int m_gt, double S_gt, float v, int
 constexpr int kCandMaxK = 1 << 20;
 __device__ __forceinline__ float cand_floor(int K)
 {
+#ifdef SMLVM_EXP_FLOOR1
+    return -1.0f;
+#endif
     const float a = 3.0f * (float)K * 0x1p-23f;
     return -((1.0f + 0x1p-23f) / (1.0f - a)) * (1.0f + 1e-5f);
 }
@@ -285,7 +288,7 @@ __device__ __forceinline__ Edge edge_pass(const Src& src, float lo, Red& red)
 // out of `red`, so control flow is uniform over the lanes that hold the row.
 template <class Src, class Red>
 __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, int nvis, int& s_out,
-                                           double& S_out)
+                                           double& S_out, int* m_robust = nullptr)
 {
     float lo = INFINITY;
     src.each([&](float v) { lo = (v > tau) ? fminf(lo, v) : lo; });
@@ -295,13 +298,14 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
     Edge b;
     for (;;) {
         b = edge_pass(src, lo, red);
-        if (b.m_gt == 0 || classify_group(b.m_gt, b.S_gt, lo, b.t) > 0) break;
+        if (__builtin_expect(b.m_gt == 0 || classify_group(b.m_gt, b.S_gt, lo, b.t) > 0, 1)) break;
         float up = INFINITY;
         src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
         lo = red.min(up);
     }
     const int m_top = b.m_gt + b.t;
     const double S_top = b.S_gt + (double)b.t * (double)lo;
+    if (m_robust) *m_robust = m_top;   // these ranks are in the support in exact arithmetic too
 
     // down through the groups the noise bound cannot decide
     int m = m_top, C = 0;
@@ -310,11 +314,11 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
     const float first_lo = vnext;
     bool open = true, dirty = false;   // open: the passing ranks so far are a prefix of the ranks
     while (vnext > -INFINITY) {
-        if (deeper_all_fail(m, S, vnext, nvis)) break;
+        if (__builtin_expect(deeper_all_fail(m, S, vnext, nvis), 1)) break;
         const Edge g = edge_pass(src, vnext, red);
         const int k = classify_group(g.m_gt, g.S_gt, vnext, g.t);
         int cnt = k > 0 ? g.t : 0;
-        if (k == 0)
+        if (__builtin_expect(k == 0, 0))
             cnt = red.sum(count_ranks_part(g.m_gt, g.S_gt, vnext, g.t, red.idx(), red.stride()));
         if (open) {
             S_at = g.S_gt + (double)cnt * (double)vnext;
@@ -328,7 +332,7 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
         vnext = g.vnext;
     }
     int s = m_top + C;
-    if (dirty) {
+    if (__builtin_expect(dirty, 0)) {
         // ranks passed below a rank that failed: the prefix sum at the count s is read off a second
         // walk over the same groups (needs two undecided groups in a row: practically never)
         int rem = C;
@@ -351,7 +355,7 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
 // must be present): Michelot iteration, then the exact edge.
 template <int E, class Red>
 __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int nvis, int& s_out,
-                                           double& S_out)
+                                           double& S_out, int* m_robust = nullptr)
 {
     // --- Michelot iteration from the lower bound tau >= -1 (z_max = 0 after the shift).
     float tau = -1.0f;
@@ -374,7 +378,7 @@ __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int nv
     // iteration's 64 lane masks alive in SGPRs across the reductions)
     asm volatile("" : "+v"(tau));
     const RegSrc<E> src{z};
-    solve_edge(src, red, tau, nvis, s_out, S_out);
+    solve_edge(src, red, tau, nvis, s_out, S_out, m_robust);
 }
 
 // ------------------------------------------------------------------------------- candidates
@@ -437,6 +441,9 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
                                                   int cap, int* cols, int colbase, int colstep)
 {
     int base = 0;
+    // opaque copy: the E column numbers derived from it must not be hoisted out of the caller's
+    // retry loop (64 registers, spilled, reloaded per element); they cost one add where they are used
+    asm volatile("" : "+v"(colbase));
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const bool in = z[e] > thr;
@@ -453,18 +460,32 @@ __device__ __forceinline__ int compact_candidates(const float (&z)[E], float thr
     return base;
 }
 
-// Rows with more than kCandCap elements within 1 of the maximum (narrow logit distributions): a
-// few full-width Michelot steps raise the bound tau_k <= tau first, and the candidates are taken
-// above tau_k - lazy_margin(K) instead.  The fp32 sums behind tau_k are off by far less than the
-// margin (<= 70 roundings of 2^-24 each on values in [-1, 0]), and by the argument at cand_floor
-// (with tau_k in place of -1) an element further below tau_k than (3 K + 1) 2^-23 / (1 - 3 K 2^-23)
-// cannot pass the oracle's fp32 test even by rounding, so the list still holds the whole support
-// and every element the exact edge has to look at.
+// Rows with more than kCandCap elements above the floor (narrow logit distributions): a few
+// full-width Michelot steps raise the bound tau_k <= tau first, and the candidates are taken above
+// tau_k - kLazyMargin instead.  The fp32 sums behind tau_k are off by far less than the margin
+// (<= 70 roundings of 2^-24 each on values in [-1, 0]), so the list holds the whole support.  That
+// it also holds every element the oracle's fp32 test could admit by rounding is checked AFTER the
+// search on the list (lazy_list_is_complete): with m ranks known to be in the support and
+// tau >= tau_k, an element at -u has f <= -m (u - |tau_k|), which is below the test's noise
+// 2^-23 (3 K u + 1) for every u >= |thr| once |thr| (m - 3 K 2^-23) > m |tau_k| + 2^-23.  A row
+// that fails the check (a short support under a very wide row) runs the full-width search.
 constexpr int kLazyPasses = 8;
 constexpr int kLazyTry = 2 * kCandCap;      // attempt the compaction once |{z > tau_k}| is below this
-__device__ __forceinline__ float lazy_margin(float floor_k)
+constexpr float kLazyMargin = 1e-3f;
+__device__ __forceinline__ bool lazy_list_is_complete(float thr, float tau_k, int m_robust, int K)
 {
-    return fmaxf(1e-3f, (-floor_k - 1.0f) + 1e-5f);
+    const float a = 3.0f * (float)K * 0x1p-23f;
+    const float m = (float)m_robust;
+    const float tl = fabsf(tau_k) + 1e-5f;   // |lower bound of tau|, fp32 slop of tau_k included
+    return m > a && fabsf(thr) * (m - a) > (m * tl + 0x1p-23f) * (1.0f + 1e-5f);
+}
+// the highest cut that passes the check above (-inf when none does: use the floor)
+__device__ __forceinline__ float lazy_complete_thr(float tau_k, int m_robust, int K)
+{
+    const float a = 3.0f * (float)K * 0x1p-23f;
+    const float m = (float)m_robust;
+    const float tl = fabsf(tau_k) + 1e-5f;
+    return m > a ? -((m * tl + 0x1p-23f) * (1.0f + 1e-5f) / (m - a)) * (1.0f + 1e-5f) - 1e-6f : -INFINITY;
 }
 
 // The threshold of any SUBSET of a row is a lower bound of the row's threshold (more elements can
@@ -540,7 +561,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                                               bool live = true, int mark = kColsOverflow)
 {
     const float floor_k = cand_floor(K);
-    const float margin = lazy_margin(floor_k);
+    const float margin = kLazyMargin;
     float mx = z[0];
 #pragma unroll
     for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
@@ -557,6 +578,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
         const int lane = threadIdx.x & 63;
         float c[kCandPerLane];
         int cc[kCandPerLane];
+        float thr_used = floor_k, tau_used = -1.0f;   // what the final candidate list was cut at
         if constexpr (NW == 1) {
             int* ccols = list ? reinterpret_cast<int*>(cand + kCandCap) : nullptr;
             const int colbase = VEC ? lane * 4 : lane, colstep = VEC ? 256 : 64;
@@ -564,8 +586,9 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             if (n_c > kCandCap) {
                 float tau = subset_bound(lane_mx);
                 wave_lds_sync();
-                n_c = compact_candidates<E, VEC>(z, fmaxf(tau - margin, floor_k), cand, kCandCap, ccols,
-                                                 colbase, colstep);
+                thr_used = fmaxf(tau - margin, floor_k);
+                tau_used = tau;
+                n_c = compact_candidates<E, VEC>(z, thr_used, cand, kCandCap, ccols, colbase, colstep);
                 int cnt_prev = 0x7fffffff;
                 for (int pass = 0; n_c > kCandCap && pass < kLazyPasses; ++pass) {
                     int cn = 0;
@@ -582,8 +605,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
                     if (cn <= kLazyTry) {
                         wave_lds_sync();
-                        n_c = compact_candidates<E, VEC>(z, fmaxf(tau - margin, floor_k), cand, kCandCap,
-                                                         ccols, colbase, colstep);
+                        thr_used = fmaxf(tau - margin, floor_k);
+                        tau_used = tau;
+                        n_c = compact_candidates<E, VEC>(z, thr_used, cand, kCandCap, ccols, colbase,
+                                                         colstep);
                         if (n_c <= kCandCap) break;
                     }
                 }
@@ -643,7 +668,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     }
                 }
                 __syncthreads();  // the lists are rewritten by the next attempt / the next row
-                if (fast) break;
+                if (fast) { thr_used = thr; tau_used = tau; break; }
                 if (first) {   // first failure: the best wave-local subset bound, then retry
                     first = false;
                     tau = red.max(subset_bound(lane_mx));
@@ -683,7 +708,12 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
         }
         if (fast) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers
-            solve_core(c, wred, kCandCap, s_final, S_final);
+            int m_robust = 0;
+            solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
+            // a list cut above the floor must be shown to hold everything the oracle could count
+            if (thr_used > floor_k && !lazy_list_is_complete(thr_used, tau_used, m_robust, K)) fast = false;
+        }
+        if (fast) {
             if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
                 n_listed = emit_cols_from_candidates<kCandPerLane, 64>(
@@ -691,7 +721,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             }
         }
     }
-    if (!fast) solve_core(z, red, K, s_final, S_final);
+#ifdef SMLVM_EXP_NOSLOW
+    if constexpr (NW == 1)
+#endif
+    if (__builtin_expect(!fast, 0)) solve_core(z, red, K, s_final, S_final);
 
     float c_s = (float)S_final - 1.0f;
     float tau_f = c_s / (float)s_final;
@@ -1100,7 +1133,10 @@ __device__ __forceinline__ int64_t wave_row(int lane)
     }
 }
 // waves per SIMD we ask the register allocator for (E data registers + ~40 of state)
-constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? 8 : (E <= 32 ? 5 : 4); }
+#ifndef SMLVM_FWD_WPE16
+#define SMLVM_FWD_WPE16 6   // tuning knob (tools/exp_build.sh): waves per SIMD asked for E <= 16 tiles
+#endif
+constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? SMLVM_FWD_WPE16 : (E <= 32 ? 5 : 4); }
 constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 constexpr int bwd_cols_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 
@@ -1460,12 +1496,15 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
             tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
         }
         const float floor_k = cand_floor(K < kCandMaxK ? K : kCandMaxK);
-        const float margin = lazy_margin(floor_k);
+        const float margin = kLazyMargin;
         float thr = fmaxf(tau - margin, floor_k);
+        float tau_used = tau;
         float c[kCandPerLane];
         int cc[kCandPerLane];
-        bool fast = false;
+        bool fast = false, retried = false;
         int cnt_prev = 0x7fffffff, passes = 0;
+        int s_final = 1;
+        double S_final = 0.0;
         for (;;) {
             if (K > kCandMaxK) break;   // beyond the candidate floor's range: search the whole row
             int base = 0;
@@ -1524,7 +1563,18 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
                 }
             }
             __syncthreads();
-            if (fast) break;
+            if (fast) {   // every wave solves the same list: uniform decisions, no barriers
+                WaveRed<64> wred;
+                int m_robust = 0;
+                solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
+                // a list cut above the floor must be shown to hold everything the oracle could count
+                if (thr <= floor_k || lazy_list_is_complete(thr, tau_used, m_robust, K)) break;
+                fast = false;
+                if (retried) break;
+                retried = true;   // once more, cut where the check asks (a short support under a wide row)
+                thr = fmaxf(lazy_complete_thr(tau_used, m_robust, K), floor_k);
+                continue;
+            }
             bool give_up = false;
             for (;;) {
                 int cn = 0;
@@ -1538,13 +1588,10 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
             }
             if (give_up) break;
             thr = fmaxf(tau - margin, floor_k);
+            tau_used = tau;
         }
-        int s_final = 1;
-        double S_final = 0.0;
         int32_t* list = cols ? cols + row * cap : nullptr;
         if (fast) {
-            WaveRed<64> wred;
-            solve_core(c, wred, kCandCap, s_final, S_final);
             if (list) {
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
                 emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap,

@@ -51,8 +51,15 @@ def cand_floor(K):
     return F(-(u * (1.0 + 1e-6)))
 
 
+def lazy_list_is_complete(thr, tau_k, m_robust, K):
+    a = F(3.0) * F(K) * F(EPS23)
+    m = F(m_robust)
+    tl = F(abs(F(tau_k)) + F(1e-5))
+    return bool(m > a and F(abs(F(thr)) * F(m - a)) > F(F(m * tl + F(EPS23)) * F(1.0 + 1e-5)))
+
+
 def solve(zv, nvis, stats):
-    """zv: visible shifted values (max = 0).  Returns (s, S)."""
+    """zv: visible shifted values (max = 0).  Returns (s, S, m_top)."""
     z = zv.astype(F)
     tau = F(-1.0)
     cp = 1 << 60
@@ -109,18 +116,46 @@ def solve(zv, nvis, stats):
             if rem == 0:
                 break
             lo2 = g["vnext"]
-    return s, S_at
+    return s, S_at, m_top
 
 
-def model_row(x, use_floor=True, stats=None):
+def model_row(x, use_floor=True, stats=None, cap=256):
+    """use_floor: candidate path (list of the elements above the floor; when more than `cap`, the
+    lazy list above a Michelot lower bound - 1e-3 with the a-posteriori completeness check)."""
     stats = stats if stats is not None else dict(edge=0, up=0, down=0, count=0, dirty=0)
+    stats.setdefault("lazy", 0)
+    stats.setdefault("lazy_rejected", 0)
     K = x.shape[0]
     z = (x - x.max()).astype(F)
+    vis = z
     if use_floor:
-        vis = z[z > cand_floor(K)]
-    else:
-        vis = z
-    s, S = solve(vis, vis.shape[0], stats)
+        floor = cand_floor(K)
+        vis = z[z > floor]
+        if vis.shape[0] > cap:
+            # Michelot steps on the whole row until few enough remain
+            tau, cp, vis = F(-1.0), 1 << 60, z
+            for _ in range(9):
+                inn = z > tau
+                c = int(inn.sum())
+                if c >= cp:
+                    break
+                cp = c
+                tau = max(tau, F((F(z[inn].sum(dtype=F)) - F(1.0)) / F(c)))
+                if c <= 2 * cap:
+                    thr = max(F(tau - F(1e-3)), floor)
+                    lst = z[z > thr]
+                    if lst.shape[0] <= cap:
+                        stats["lazy"] += 1
+                        s, S, m_top = solve(lst, cap, stats)
+                        if thr <= floor or lazy_list_is_complete(thr, tau, m_top, K):
+                            vis = None
+                        else:
+                            stats["lazy_rejected"] += 1
+                        break
+            if vis is None:
+                tau_f = F(F(F(S) - F(1.0)) / F(s))
+                return np.maximum(z - tau_f, F(0)).astype(F), s, tau_f
+    s, S, _ = solve(vis, vis.shape[0], stats)
     tau = F(F(F(S) - F(1.0)) / F(s))
     p = np.maximum(z - tau, F(0)).astype(F)
     return p, s, tau
@@ -183,7 +218,8 @@ def main():
                            p=[.1, .1, .1, .15, .15, .12, .1, .1, .05, .03]))
         x = gen_row(rng, K)
         p_ref, s_ref, tau_ref, _ = oracle.sparsemax_fwd(x[None])
-        p, s, tau = model_row(x, use_floor=bool(rng.integers(0, 2)), stats=stats)
+        p, s, tau = model_row(x, use_floor=bool(rng.integers(0, 2)), stats=stats,
+                              cap=int(rng.choice([8, 32, 256])))
         n += 1
         if s != s_ref[0] or tau != tau_ref[0] or not np.array_equal(p, p_ref[0]):
             bad += 1
