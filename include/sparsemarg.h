@@ -104,6 +104,17 @@ int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, int64_t R, v
                           size_t workspace_bytes, void* stream);
 int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* rows, int32_t* cols,
                           float* vals, int64_t R, int32_t K, void* stream);
+/* smlvm_support_offsets without a workspace argument.  No counterpart in the reference: it exists
+ * for callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The block sums of the scan live in a static device
+ * array of the library (64 KiB per GPU, held until the process ends), so R is limited to
+ * SMLVM_NOALLOC_MAX_ROWS rows (SMLVM_ERR_UNSUPPORTED beyond).  Same result as
+ * smlvm_support_offsets, bit for bit.  Nothing is allocated or freed inside (the first call on a
+ * device looks the array's address up once, with that device current).  Every call on one GPU
+ * uses that GPU's one array: calls that overlap on the same GPU (two streams) race -- serialise
+ * them, or use smlvm_support_offsets with a workspace per stream. */
+#define SMLVM_NOALLOC_MAX_ROWS (1 << 24)
+int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_offsets, int64_t R, void* stream);
 /* The same two steps from the forward's support lists (smlvm_sparsemax_fwd_cols): rows that have
  * a list are counted / compacted from its <= cap entries (sorted by column on the fly, so the
  * output order is unchanged) and only gather their probabilities; rows marked -2 are scanned.

@@ -8,6 +8,8 @@
 // the in-row ordered positions; 128-byte groups with no positive entry are skipped wave-uniformly.
 #include "common.hpp"
 
+#include <mutex>
+
 namespace smlvm {
 
 constexpr int kScanItemsPerBlock = 2048;  // 256 threads x 8 items
@@ -340,6 +342,58 @@ extern "C" int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, i
         return SMLVM_ERR_WORKSPACE;
     const int64_t nblocks = (R + kScanItemsPerBlock - 1) / kScanItemsPerBlock;
     long long* sums = (long long*)workspace;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, R);
+    hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(256), 0, st, sums, nblocks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, row_offsets, R);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------------------- no-allocation
+// smlvm_support_offsets_noalloc: the same three launches with the block sums in a file-scope device
+// array instead of a caller workspace, for callers that cannot allocate (HIP graph capture, tight
+// serving loops).  `scratch` below is a HOST-SIDE STAND-IN for the device array, not a
+// device address: its address on the current device comes from hipGetSymbolAddress, once per
+// device, and only that pointer is ever handed to a kernel.
+constexpr int64_t kNoAllocMaxRows = (int64_t)SMLVM_NOALLOC_MAX_ROWS;
+constexpr int kNoAllocSums = (int)(kNoAllocMaxRows / kScanItemsPerBlock);   // 8192 block sums = 64 KiB
+static __device__ __align__(256) long long scratch[kNoAllocSums];
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static long long* g_scratch_ptr[kMaxDevices];   // per device: each GPU holds its own copy of the array
+
+static long long* offsets_scratch_on_current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            smlvm::g_last_hip_error = (int)e;
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = (long long*)ptr;
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_offsets, int64_t R,
+                                             void* stream)
+{
+    if (R < 0 || !row_offsets) return SMLVM_ERR_INVALID;
+    if (R > kNoAllocMaxRows) return SMLVM_ERR_UNSUPPORTED;   // beyond the static block-sum array
+    hipStream_t st = (hipStream_t)stream;
+    if (R == 0) {
+        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        return SMLVM_OK;
+    }
+    if (!nnz) return SMLVM_ERR_INVALID;
+    long long* sums = offsets_scratch_on_current_device();
+    if (!sums) return SMLVM_ERR_HIP;
+    // every block sum the later launches read is written by the first one: nothing has to be cleared
+    const int64_t nblocks = (R + kScanItemsPerBlock - 1) / kScanItemsPerBlock;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, R);
     hipLaunchKernelGGL(scan_of_sums_kernel, dim3(1), dim3(256), 0, st, sums, nblocks);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, nnz, sums, row_offsets, R);

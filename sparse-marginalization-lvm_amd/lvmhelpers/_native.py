@@ -19,6 +19,7 @@ ABI_SYMBOLS = [
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
+    "smlvm_support_offsets_noalloc",
     "smlvm_sparsemax_support_mask_bytes", "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
     "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
