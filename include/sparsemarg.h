@@ -191,6 +191,9 @@ int smlvm_unpack_configs(const uint32_t* aset_bits, const int32_t* rows, const i
  *   logits[n,f,c] = b[c] + sum_r x[n,f,r] w[c,r];   loss[n] = sum_f (logsumexp_c logits - logits[n,f,y[n,f]])
  *   x [N,F,R] fp32, w [C,R] fp32 (nn.Linear weight), b [C] fp32, y [N,F] labels in [0,C)
  *   y_kind: 0 = uint8, 1 = int32, 2 = int64.   Limits: R <= 8, C <= 256.
+ *   A label outside [0, C) never indexes w or b: the forward writes NaN into that pair's nll (hence
+ *   the row's loss), the backward NaN into its dx; the reference's F.cross_entropy raises a device
+ *   assert in that case (experiments/bit_vector-vae/train.py:368).
  *   fwd outputs: lse [N,F] fp32 (saved for the backward), nll [N,F] fp32, loss [N] fp32 (nullable)
  *   bwd: gloss [N] = dL/dloss;  dx [N,F,R], dw [C,R], db [C] (each nullable); workspace of
  *        smlvm_lowrank_ce_bwd_workspace_bytes bytes for the per-block dw/db partials.

@@ -29,10 +29,15 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __buil
 // raw v_exp_f32: arguments here are <= 0 (or bounded), results that underflow may flush to 0
 __device__ __forceinline__ float ex2(float v) { return __builtin_amdgcn_exp2f(v); }
 
+// Label of pair i, or -1 when it is outside [0, C): nothing is ever indexed with such a label (the
+// reference's F.cross_entropy raises a device assert there, experiments/bit_vector-vae/train.py:368);
+// the forward turns it into a NaN loss for that row, the backward into NaN dx, and the one-hot term
+// of dW / db simply matches no class.
 template <typename YT>
-__device__ __forceinline__ int label_at(const void* y, int64_t i)
+__device__ __forceinline__ int label_at(const void* y, int64_t i, int C)
 {
-    return (int)static_cast<const YT*>(y)[i];
+    const long long v = (long long)static_cast<const YT*>(y)[i];
+    return (v >= 0 && v < (long long)C) ? (int)v : -1;
 }
 
 // Every lane carries TWO (row, feature) pairs -- p and p + 256 of the block's 512 -- so that the
@@ -131,9 +136,9 @@ __global__ __launch_bounds__(256) void lowrank_ce_fwd_kernel(
         float L = fmaf(log2f(sh), kLn2, bh);
         if (!(sh > 1e-18f)) L = lse_exact<R>(x, h, W, b, C);   // also catches NaN
         if (live[h]) {
-            const int yy = label_at<YT>(y, p[h]);
+            const int yy = label_at<YT>(y, p[h], C);
             lse[p[h]] = L;
-            nll[p[h]] = L - logit_at<R>(x, h, W, b, yy);
+            nll[p[h]] = yy >= 0 ? L - logit_at<R>(x, h, W, b, yy) : __builtin_nanf("");
         }
     }
 }
@@ -185,11 +190,11 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dx_kernel(
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (!live[h]) continue;
-        const int yy = label_at<YT>(y, p[h]);
+        const int yy = label_at<YT>(y, p[h], C);
         const float g = gloss[p[h] / F];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            dX[p[h] * R + r] = g * ((h ? dx[r].y : dx[r].x) - W[yy * R + r]);
+            dX[p[h] * R + r] = yy >= 0 ? g * ((h ? dx[r].y : dx[r].x) - W[yy * R + r]) : __builtin_nanf("");
     }
 }
 
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
             const int64_t p = ok ? p0 + threadIdx.x : p0;
             ls[threadIdx.x] = lse[p] * kLog2e;
             gs[threadIdx.x] = ok ? gloss[p / F] : 0.0f;   // padding contributes nothing
-            ys[threadIdx.x] = ok ? label_at<YT>(y, p) : -1;
+            ys[threadIdx.x] = ok ? label_at<YT>(y, p, C) : -1;
         }
         __syncthreads();
 #pragma unroll 2

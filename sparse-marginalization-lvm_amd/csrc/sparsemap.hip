@@ -26,6 +26,8 @@
 // dominate: 9.5 KB at n = 32, 141 KB at n = 128 (one sample per CU at a time).
 #include "common.hpp"
 
+#include <atomic>
+
 #include <math.h>
 
 namespace smlvm {
@@ -782,6 +784,27 @@ __global__ __launch_bounds__(64) void sparsemap_bwd_kernel(
 
 using namespace smlvm;
 
+constexpr int kMaxDevices = 64;
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+// compute units of the current device (per device: a process may drive several GPUs)
+static int device_cus()
+{
+    static std::atomic<int> cus[kMaxDevices];
+    const int dev = current_device();
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0)
+            c = 256;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
 struct SmArgs {
     const float* scores; const double* init_scores; int32_t budget, max_iter; int64_t B; int32_t n;
     uint32_t* aset_bits; float* p; int32_t* alen; double* a_out; int32_t* iters; int32_t* status;
@@ -793,15 +816,17 @@ static int launch_sm_fwd(const SmArgs& a, int resume)
 {
     using L = SmLayout<LD, WT, NK>;
     static_assert(L::total <= 160 * 1024, "LDS per CU");
-    static thread_local bool configured = false;
-    if (L::total > 48 * 1024 && !configured) {
+    // the attribute belongs to (kernel, device): remember it per device, not per thread
+    static std::atomic<bool> configured[kMaxDevices];
+    const int dev = current_device();
+    if (L::total > 48 * 1024 && !configured[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel<LD, WT, NK>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)L::total) != hipSuccess) {
             g_last_hip_error = (int)hipGetLastError();
             return SMLVM_ERR_HIP;
         }
-        configured = true;
+        configured[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK>), dim3((unsigned)a.B), dim3(64), L::total,
                        a.stream, a.scores, a.init_scores, a.budget, a.max_iter, a.B, a.n,
@@ -862,13 +887,7 @@ extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_score
     a.ws_vec = reinterpret_cast<double*>(w);
     w += align256(sizeof(double) * 3 * ldo * (size_t)B);
     if (!inv_a) a.a_out = reinterpret_cast<double*>(w);
-    static thread_local int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cus();
     int rc;
     if (B > 4 * (int64_t)cus) {
         rc = launch_sm_fwd<kTier0, 4, 2>(a, 0);

@@ -119,7 +119,8 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
     if want_mask:
         nbytes = lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K))
         if nbytes:
-            mask = torch.empty(nbytes // 4, dtype=torch.int32, device=x.device)
+            # zeroed: a row is only ever marked -3 after its bits were written, this is defence
+            mask = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
                                               _p(cols), _i32(SUPPORT_COLS_CAP), _p(mask), _i64(R),

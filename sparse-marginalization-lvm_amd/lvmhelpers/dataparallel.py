@@ -33,7 +33,8 @@ def shard_rows(tensor, rank=None, world=None, dim=0):
 def global_init_scores(batch_total, n, rank, world, device, seed=None):
     """SparseMAP init scores for the rank's shard of a GLOBAL batch: every rank draws the whole
     [batch_total, 2n] fp64 block from the same CPU stream (as lvmhelpers/sparsemap.py:26 would for
-    the unsharded batch) and keeps its rows, so results do not depend on the world size."""
+    the unsharded batch; seed=None: torch's global CPU generator, which equal seeds keep in step
+    on all ranks) and keeps its rows, so results do not depend on the world size."""
     g = None
     if seed is not None:
         g = torch.Generator().manual_seed(seed)
@@ -42,19 +43,49 @@ def global_init_scores(batch_total, n, rank, world, device, seed=None):
     return full[lo:hi].to(device)
 
 
+def current_shard(local_batch):
+    """(rank, world, batch_total) of this process when torch.distributed runs with more than one
+    rank and equal shards, else None."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        return dist.get_rank(), world, local_batch * world
+    return None
+
+
 @torch.no_grad()
-def allreduce_gradients(parameters, group=None):
-    """Average the gradients over all ranks with ONE all-reduce of a flat fp32 bucket."""
-    params = [p for p in parameters if p.grad is not None]
+def allreduce_gradients(parameters, group=None, local_rows=None):
+    """Global-batch gradient from the ranks' local-batch gradients with ONE all-reduce of a flat
+    fp32 bucket.
+
+    The bucket covers EVERY parameter that requires grad, in the same order on every rank; a
+    parameter without a gradient on this rank (a decoder branch no row of the shard used)
+    contributes zeros and gets the reduced gradient back, so bucket lengths never differ between
+    ranks.  ``local_rows``: this rank's batch size.  The reference normalises a loss by the LOCAL
+    batch (lvmhelpers/marg.py:126, structmarg.py:140,242), so the global-batch gradient is
+    sum_r rows_r * grad_r / sum_r rows_r: the row counts ride along in the same bucket.  Without
+    it the shards are taken to be equal (plain mean over ranks).  Returns the bytes exchanged.
+    """
+    params = [p for p in parameters if p.requires_grad]
     if not dist.is_initialized() or dist.get_world_size(group) == 1 or not params:
         return 0
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in params])
+    dev = params[0].device
+    weight = 1.0 if local_rows is None else float(local_rows)
+    parts = [(p.grad.reshape(-1).to(torch.float32) if p.grad is not None
+              else torch.zeros(p.numel(), dtype=torch.float32, device=dev)) for p in params]
+    parts.append(torch.full((1,), weight, dtype=torch.float32, device=dev))
+    flat = torch.cat(parts)
+    if local_rows is not None:
+        flat[:-1].mul_(weight)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(dist.get_world_size(group))
+    flat[:-1].div_(flat[-1])     # sum of the weights: the world size, or the global row count
     off = 0
     for p in params:
-        k = p.grad.numel()
-        p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        k = p.numel()
+        g = flat[off:off + k].view_as(p)
+        if p.grad is None:
+            p.grad = g.to(p.dtype).clone()
+        else:
+            p.grad.copy_(g)
         off += k
     return flat.numel() * 4
 

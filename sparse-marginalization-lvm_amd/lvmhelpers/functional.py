@@ -156,13 +156,18 @@ SUPPORT_ATTR = "_smlvm_support_cols"
 def _tag_support(p, cols):
     """Hang the forward's support lists on the probability tensor itself, so that a later
     `_native.support_compact(p.detach(), support_cols=support_cols_of(p))` does not have to scan p
-    again.  The tag lives on this tensor object only (views, detach() and arithmetic drop it)."""
-    setattr(p, SUPPORT_ATTR, cols)
+    again.  The tag lives on this tensor object only (views, detach() and arithmetic drop it) and
+    records the tensor's storage and version counter: an in-place change of p afterwards (masking,
+    renormalising, clamp_) makes the lists stale, and support_cols_of then returns None."""
+    setattr(p, SUPPORT_ATTR, (cols, p.data_ptr(), p._version))
 
 
 def support_cols_of(p):
-    cols = getattr(p, SUPPORT_ATTR, None)
-    if cols is not None and (p.dim() != 2 or cols.shape[0] != p.shape[0]):
+    tag = getattr(p, SUPPORT_ATTR, None)
+    if tag is None:
+        return None
+    cols, ptr, version = tag
+    if p.dim() != 2 or cols.shape[0] != p.shape[0] or p.data_ptr() != ptr or p._version != version:
         return None
     return cols
 

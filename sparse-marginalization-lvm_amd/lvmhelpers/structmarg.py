@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _native
+from . import dataparallel
 from . import functional as F_
 
 
@@ -115,16 +116,31 @@ class SparseMAPWrapper(nn.Module):
         self.init = init
         self.max_iter = max_iter
         self._idx_tensor = None
+        # Data-parallel runs: (rank, world, batch_total) of the shard this module sees.  None = ask
+        # torch.distributed (equal shards), or the whole batch when it is not initialised.
+        self.shard = None
+
+    def _init_scores(self, batch_size, latent_size, device):
+        # the reference draws torch.rand(2n, dtype=double) from the global CPU generator once per
+        # sample (sparsemap.py:25-27); one [B, 2n] draw consumes the same stream.  Sharded over
+        # ranks, every rank draws the block of the GLOBAL batch (same seed -> same stream) and
+        # keeps its rows, so a sample's init scores -- hence its active set -- do not depend on
+        # the world size.
+        shard = self.shard if self.shard is not None else dataparallel.current_shard(batch_size)
+        if shard is None:
+            return torch.rand(batch_size, 2 * latent_size, dtype=torch.double).to(device)
+        rank, world, batch_total = shard
+        init_scores = dataparallel.global_init_scores(batch_total, latent_size, rank, world, device)
+        if init_scores.shape[0] != batch_size:
+            raise ValueError(f"SparseMAPWrapper.shard {shard} does not describe a batch of {batch_size}")
+        return init_scores
 
     def forward(self, *args, **kwargs):
         scores = self.agent(*args, **kwargs)
         batch_size, latent_size = scores.shape
         init_scores = None
         if self.init:
-            # the reference draws torch.rand(2n, dtype=double) from the global CPU generator once
-            # per sample (sparsemap.py:25-27); one [B, 2n] draw consumes the same stream
-            init_scores = torch.rand(
-                batch_size, 2 * latent_size, dtype=torch.double).to(scores.device)
+            init_scores = self._init_scores(batch_size, latent_size, scores.device)
         p, aset_bits, alen, _, _ = F_.sparsemap_batched(
             scores, init_scores, self.budget, self.max_iter)
 

@@ -190,12 +190,43 @@ def gold_sparsemap_marg(ref):
             meta=np.array([B, D, n, budget, int(init), 13]))
 
 
+def gold_common_params(ref):
+    """The reference's own populate_common_params (lvmhelpers/utils.py:20-99) applied to a fresh
+    parser: every flag with its type, default, choices and action kind, the namespace of an empty
+    command line and of the command lines the published scripts use."""
+    import argparse
+    import json
+    parser = argparse.ArgumentParser()
+    ref["utils"].populate_common_params(parser)
+    flags = []
+    for a in parser._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        flags.append(dict(flags=a.option_strings, dest=a.dest, kind=type(a).__name__,
+                          type=None if a.type is None else a.type.__name__, default=a.default,
+                          choices=None if a.choices is None else list(a.choices), nargs=a.nargs))
+    lines = [[], ["--mode", "marg", "--normalizer", "sparsemax", "--latent_size", "256", "--entropy_coeff", "0.1"],
+             ["--mode", "sparsemap", "--budget", "16", "--noinit", "--batch_size", "64", "--latent_size", "32"],
+             ["--mode", "topksparse", "--topksparse", "10", "--lr", "0.002", "--no_cuda"],
+             ["--mode", "gs", "--gs_tau", "0.5", "--straight_through", "--random_seed", "7"]]
+    parsed = [dict(argv=argv, namespace=vars(parser.parse_args(argv))) for argv in lines]
+    with open(os.path.join(HERE, "common_params.json"), "w") as f:
+        json.dump(dict(flags=flags, parsed=parsed), f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "needs /root/reference"
     oracle.build()
-    gold_binary_topk()
+    only = sys.argv[1:]          # e.g. `make_goldens.py common_params`: regenerate just that fixture
     ref = _load_reference()
-    gold_marg(ref)
-    gold_topk_marg(ref)
-    gold_sparsemap_marg(ref)
+    if not only or "binary_topk" in only:
+        gold_binary_topk()
+    if not only or "marg" in only:
+        gold_marg(ref)
+    if not only or "topk_marg" in only:
+        gold_topk_marg(ref)
+    if not only or "sparsemap_marg" in only:
+        gold_sparsemap_marg(ref)
+    if not only or "common_params" in only:
+        gold_common_params(ref)
     print("goldens written to", HERE)

@@ -66,9 +66,63 @@ def test_two_ranks_equal_global_batch():
     _local_loss(model, x).backward()
     ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
     assert np.allclose(grads[0], ref, atol=1e-7)
-    assert grads[1] == 4 * ref.size and grads[2] == 0.5
+    assert grads[1] == 4 * (ref.size + 1) and grads[2] == 0.5
     full = torch.rand(8, 8, dtype=torch.double, generator=torch.Generator().manual_seed(42)).numpy()
     assert np.array_equal(np.concatenate([inits[0], inits[1]]), full)
+
+
+def _bitvae_params():
+    """Parameter shapes of the config-5 model (bench_models.make_bitvae: 784-128-128 encoder,
+    128-128-3920 generator + rank-5 -> 256-way output layer): the bucket a SparseMAPMarg step pushes."""
+    torch.manual_seed(3)
+    shapes = [(128, 784), (128,), (128, 128), (128,), (128, 128), (128,), (3920, 128), (3920,), (256, 5), (256,)]
+    return [torch.nn.Parameter(torch.randn(*s) * 0.01) for s in shapes]
+
+
+def _rank_grad(param_index, shape, rank):
+    g = torch.Generator().manual_seed(100 * rank + param_index)
+    return torch.randn(*shape, generator=g)
+
+
+def _worker_bucket(rank, world, port, out):
+    from lvmhelpers import dataparallel as dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    params = _bitvae_params()
+    rows = [5, 3][rank]                              # unequal shards of a global batch of 8
+    for i, p in enumerate(params):
+        if not (rank == 1 and i in (8, 9)):          # rank 1 never used the output layer
+            p.grad = _rank_grad(i, p.shape, rank)
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    nbytes = dp.allreduce_gradients(params + [frozen], local_rows=rows)
+    shard = dp.current_shard(4)
+    if rank == 1:
+        out.put((torch.cat([p.grad.reshape(-1) for p in params]).numpy(), nbytes, shard, frozen.grad is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config5_shaped_bucket_with_missing_grads_and_unequal_shards():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bucket, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, nbytes, shard, frozen_untouched = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    params = _bitvae_params()
+    ref = []
+    for i, p in enumerate(params):
+        g0 = _rank_grad(i, p.shape, 0) * 5
+        g1 = torch.zeros_like(g0) if i in (8, 9) else _rank_grad(i, p.shape, 1) * 3
+        ref.append(((g0 + g1) / 8).reshape(-1))
+    ref = torch.cat(ref).numpy()
+    assert got.shape == ref.shape and np.allclose(got, ref, rtol=1e-6, atol=1e-7)
+    assert nbytes == 4 * (ref.size + 1)              # one bucket: every parameter + the row count
+    assert shard == (1, 2, 8) and frozen_untouched
 
 
 def test_shard_ranges_cover_and_partition():

@@ -130,3 +130,21 @@ def test_compact_from_support_lists(dev, R, K, sigma):
     # compaction from lists whose overflow rows carry the mask mark
     off2, rows2, cols2, vals2 = _native.support_compact(p, support_cols=tagged)
     assert torch.equal(off2, off0) and torch.equal(cols2, cols0) and torch.equal(vals2, vals0)
+
+
+def test_support_tag_goes_stale_when_p_is_modified(dev):
+    """The support lists ride on the probability tensor as a Python attribute; an in-place change of
+    p afterwards must invalidate them (compaction would otherwise list the old support)."""
+    import torch
+    from lvmhelpers import functional as F_, _native
+    x = torch.randn(32, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    p = F_.sparsemax(x, dim=-1)
+    assert F_.support_cols_of(p) is not None
+    off0, rows0, cols0, _ = _native.support_compact(p, support_cols=F_.support_cols_of(p))
+    off1, rows1, cols1, _ = _native.support_compact(p)
+    assert torch.equal(rows0, rows1) and torch.equal(cols0, cols1) and torch.equal(off0, off1)
+    p[:, :32] = 0.0                                   # masks half of the categories in place
+    assert F_.support_cols_of(p) is None
+    _, rows2, cols2, _ = _native.support_compact(p, support_cols=F_.support_cols_of(p))
+    assert int(cols2.max()) >= 32 and int(cols2.min()) >= 32
+    assert F_.support_cols_of(p.clone()) is None and F_.support_cols_of(p.detach()) is None

@@ -119,3 +119,26 @@ def test_segmented_logsumexp(dev, B, maxlen):
     assert np.array_equal(np.isinf(got), np.isinf(ref))
     ok = ~np.isinf(ref)
     np.testing.assert_allclose(got[ok], ref[ok], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("ydtype,bad", [(torch.int64, -1), (torch.int64, 10), (torch.int32, 1 << 20), (torch.uint8, 200)])
+def test_lowrank_nll_label_out_of_range_is_loud_and_safe(dev, ydtype, bad):
+    """A label outside [0, C) (F.cross_entropy raises a device assert for it in the reference,
+    train.py:368) never indexes the weights: that row's loss and dx come out NaN, every other row,
+    dW and db are what they are without the bad pair's one-hot term."""
+    from lvmhelpers import functional as F_
+    N, Fe, C, R = 6, 40, 10, 3
+    x, w, b, y, gl = _problem(N, Fe, C, R, 5, ydtype)
+    y_bad = y.clone()
+    y_bad[2, 7] = bad
+    xd = x.to(dev).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    lv = F_.lowrank_categorical_nll(xd, wd, b.to(dev), y_bad.to(dev))
+    good = F_.lowrank_categorical_nll(x.to(dev), w.to(dev), b.to(dev), y.to(dev))
+    assert bool(torch.isnan(lv[2])) and bool(torch.isfinite(lv[[0, 1, 3, 4, 5]]).all())
+    assert torch.equal(lv[[0, 1, 3, 4, 5]], good[[0, 1, 3, 4, 5]])
+    gl0 = torch.ones(N, device=dev)
+    gl0[2] = 0.0                                # keep the NaN row out of the upstream gradient
+    (torch.nan_to_num(lv) * gl0).sum().backward()
+    assert bool(torch.isfinite(wd.grad).all())
+    assert bool(torch.isfinite(xd.grad[[0, 1, 3, 4, 5]]).all())

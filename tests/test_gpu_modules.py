@@ -125,6 +125,130 @@ def test_per_sample_smap_api(dev, oracle_mod):
     assert torch.all(aset2.sum(-1) <= 3) and abs(float(p2.detach().sum()) - 1) < 1e-6
 
 
+@pytest.mark.parametrize("budget", [0, 3])
+def test_pfactor_call_sequence(dev, oracle_mod, budget):
+    """PFactorBernoulli / PFactorBudget driven exactly as the reference's run_sparsemap / jv drive
+    them (lvmhelpers/sparsemap.py:15-30,42): initialize -> init_active_set_from_scores -> solve_qp
+    -> get_sparse_solution -> dist_jacobian_vec, on host arrays, against the oracle."""
+    from lvmhelpers.pbernoulli import PFactorBernoulli
+    from lvmhelpers.pbudget import PFactorBudget
+    n = 7
+    x = torch.randn(n, generator=torch.Generator().manual_seed(9))
+    f = PFactorBudget() if budget else PFactorBernoulli()
+    f.initialize(n, budget) if budget else f.initialize(n)
+    x_np = np.concatenate([x.numpy().astype(np.double), np.zeros(n)])            # sparsemap.py:21-22
+    init = torch.rand(2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(4))
+    f.init_active_set_from_scores(init, [])                                      # sparsemap.py:27
+    post, add = f.solve_qp(x_np, [], max_iter=100)                               # sparsemap.py:29
+    aset, p = f.get_sparse_solution()                                            # sparsemap.py:30
+    p = p[:len(aset)]
+    ref = oracle_mod.sparsemap_fwd(x.numpy()[None], init.numpy()[None], budget, 100)
+    m = int(ref["alen"][0])
+    assert len(aset) == m and all(len(c) == n and set(c) <= {0, 1} for c in aset)
+    assert np.array_equal(np.asarray(aset, np.float32), oracle_mod.unpack_bits(ref["aset_bits"][0, :m], n))
+    assert np.array_equal(np.asarray(p, np.float32), ref["p"][0, :m])
+    mu = (np.asarray(p)[:, None] * np.asarray(aset)).sum(0)
+    assert post.shape == (2 * n,) and add.shape == (0,)
+    np.testing.assert_allclose(post[:n], mu, atol=1e-7)
+    np.testing.assert_allclose(post[:n] + post[n:], np.full(n, np.sum(p)), atol=1e-7)
+    if budget == 0:                                                              # closed form (SURVEY 8(a) a8)
+        np.testing.assert_allclose(post[:n], np.clip((x.numpy().astype(np.float64) + 1) / 2, 0, 1), atol=1e-6)
+    else:
+        assert all(sum(c) <= budget for c in aset)
+    dp = np.random.default_rng(2).standard_normal(m).astype(np.float32)
+    d_eta_u = np.empty(2 * n, dtype=np.float32)                                  # sparsemap.py:40-42
+    d_eta_v = np.empty(0, dtype=np.float32)
+    f.dist_jacobian_vec(dp, d_eta_u, d_eta_v)
+    g = np.zeros((1, n + 1), np.float32)
+    g[0, :m] = dp
+    want = oracle_mod.sparsemap_bwd(g, ref["aset_bits"], ref["alen"], ref["invA"], n)[0]
+    np.testing.assert_allclose(d_eta_u[:n], want, atol=1e-6)
+    # potentials on both halves: only their difference matters; an unrepresentable one is refused
+    f2 = PFactorBudget() if budget else PFactorBernoulli()
+    f2.initialize(n, budget) if budget else f2.initialize(n)
+    f2.init_active_set_from_scores(init, [])
+    post2, _ = f2.solve_qp(np.concatenate([x_np[:n] + 0.5, np.full(n, 0.5)]), [], max_iter=100)
+    np.testing.assert_allclose(post2, post, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        f2.solve_qp(np.concatenate([np.full(n, 1.0 / 3.0), np.zeros(n)]), [], max_iter=10)
+    with pytest.raises(ValueError):
+        f2.solve_qp(np.zeros(2 * n + 1), [], max_iter=10)
+
+
+def test_autograd_class_names(dev, oracle_mod):
+    """SparseMAP / BernSparseMAP / BudgetSparseMAP are importable and callable the way the
+    reference's entry points call them (sparsemap.py:151-156), factor kept on ctx."""
+    from lvmhelpers import sparsemap as sm
+    assert issubclass(sm.BernSparseMAP, sm.SparseMAP) and issubclass(sm.BudgetSparseMAP, sm.SparseMAP)
+    x = torch.randn(6, generator=torch.Generator().manual_seed(3)).to(dev).requires_grad_(True)
+    torch.manual_seed(5)
+    p, aset = sm.BernSparseMAP.apply(x, 100, True)
+    torch.manual_seed(5)
+    p_b, aset_b = sm.bernoulli_smap(x)
+    assert torch.equal(p, p_b) and torch.equal(aset, aset_b) and not aset.requires_grad
+    w = torch.randn(p.shape[0], generator=torch.Generator().manual_seed(1)).to(dev)
+    (gx,) = torch.autograd.grad((p * w).sum(), x)
+    torch.manual_seed(5)
+    init = torch.rand(12, dtype=torch.double).numpy()[None]
+    ref = oracle_mod.sparsemap_fwd(x.detach().cpu().numpy()[None], init, 0, 100)
+    g = np.zeros((1, 7), np.float32)
+    g[0, :p.shape[0]] = w.cpu().numpy()
+    want = oracle_mod.sparsemap_bwd(g, ref["aset_bits"], ref["alen"], ref["invA"], 6)[0]
+    np.testing.assert_allclose(gx.cpu().numpy(), want, atol=1e-6)
+    p2, aset2 = sm.BudgetSparseMAP.apply(x, 2, 100, False)
+    assert torch.all(aset2.sum(-1) <= 2) and abs(float(p2.sum()) - 1) < 1e-6
+    with pytest.raises(NotImplementedError):
+        sm.sequence_smap(x, x[:-1])
+
+
+def test_sparsemap_wrapper_is_world_size_independent(dev):
+    """Data parallel: a batch of 128 solved whole, and as two 64-row shards whose init scores are
+    the rank's rows of the GLOBAL draw (SparseMAPWrapper.shard -> dataparallel.global_init_scores):
+    identical idxs / distr / support, and the row-weighted shard gradients equal the whole-batch
+    gradient.  (The encoder is elementwise so the scores of a row do not depend on its batch.)"""
+    from lvmhelpers.structmarg import SparseMAPMarg, SparseMAPWrapper
+    from lvmhelpers.utils import DeterministicWrapper
+    from toy_models import BitDecoder, _seeded
+    B, n = 128, 32
+
+    class Elem(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.full((n,), 1.5))
+            self.b = torch.nn.Parameter(torch.zeros(n))
+
+        def forward(self, x):
+            return x * self.w + self.b
+
+    x = torch.randn(B, n, generator=torch.Generator().manual_seed(21)).to(dev)
+
+    def run(rows, shard):
+        enc, dec = Elem().to(dev), _seeded(BitDecoder(n, n), 17).to(dev)
+        wrap = SparseMAPWrapper(enc, budget=0, init=True)
+        wrap.shard = shard
+        model = SparseMAPMarg(wrap, DeterministicWrapper(dec), bit_loss, encoder_entropy_coeff=1.0)
+        torch.manual_seed(33)                       # every rank starts from the same CPU stream
+        out = model(x[rows], x[rows], x[rows])
+        out["loss"].backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in list(enc.parameters()) + list(dec.parameters())])
+        return out, grads
+
+    whole, g_whole = run(slice(0, B), None)
+    parts = [run(slice(r * 64, (r + 1) * 64), (r, 2, B)) for r in range(2)]
+    idxs = [i + 64 * r for r, (o, _) in enumerate(parts) for i in o["log"]["idxs"]]
+    assert idxs == whole["log"]["idxs"]
+    assert torch.equal(torch.cat([o["log"]["distr"] for o, _ in parts]), whole["log"]["distr"])
+    assert torch.equal(torch.cat([o["log"]["support"] for o, _ in parts]), whole["log"]["support"])
+    g_parts = sum(64 / B * g for _, g in parts)
+    assert float((g_parts - g_whole).abs().max()) <= 2e-5 * max(1.0, float(g_whole.abs().max()))
+    # without the shard description the two shards would both draw rows 0..63 of the stream
+    same, _ = run(slice(64, 128), None)
+    assert same["log"]["idxs"] != parts[1][0]["log"]["idxs"] or not torch.equal(
+        same["log"]["distr"], parts[1][0]["log"]["distr"])
+    with pytest.raises(ValueError):
+        run(slice(0, 60), (0, 2, B))
+
+
 def test_entmax_shim(dev, oracle_mod):
     import entmax
     rng = np.random.default_rng(0)

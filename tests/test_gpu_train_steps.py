@@ -50,3 +50,34 @@ def test_fused_decoder_equals_dense_logits(dev):
     assert abs(l0 - l1) <= 3e-6 * abs(l1)
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 5e-5 * max(1.0, float(b.abs().max()))
+
+
+def test_config5_step_at_the_per_gpu_batch(dev):
+    """BASELINE.json configs[4] as ONE step at its per-GPU shape: 1024 samples at 128 bits through
+    SparseMAPMarg (batched active-set solver, compaction, bit unpacking, fused rank-5 decoder loss
+    over ~50k support rows, weighted reduction, backward through all of it, Adam).  Checks the
+    step's own invariants: sum of each sample's distribution is 1, support lists consistent, every
+    parameter gets a finite gradient, and three steps lower the loss."""
+    import bench_models as bm
+    torch.manual_seed(2)
+    model, batch = bm.make_bitvae(dev, 1024, 128, "sparsemap", seed=0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.zero_grad(set_to_none=True)
+    out = model(*batch)
+    out["loss"].backward()
+    lg = out["log"]
+    idx = torch.tensor(lg["idxs"], device=dev)
+    N = idx.numel()
+    assert lg["distr"].shape == (N,) and lg["loss_output"].shape == (N,)
+    assert lg["support"].shape == (1024,) and int(lg["support"].sum()) == N
+    assert bool((idx[1:] >= idx[:-1]).all()) and int(idx[0]) == 0 and int(idx[-1]) == 1023
+    assert torch.equal(torch.bincount(idx, minlength=1024).float().cpu(), lg["support"].cpu())
+    sums = torch.zeros(1024, device=dev, dtype=torch.float64).index_add_(0, idx, lg["distr"].double())
+    assert float((sums - 1).abs().max()) <= 1e-3          # see DESIGN section 4 on near-singular insertions
+    assert float((sums - 1).abs().median()) <= 1e-6
+    assert bool((lg["distr"] > 0).all())
+    for p in model.parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all())
+    opt.step()
+    losses = [float(out["loss"])] + [float(bm.train_step(model, opt, batch)["loss"]) for _ in range(3)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
