@@ -33,7 +33,27 @@
  *       null-space configuration via an eigendecomposition; unreachable in exact arithmetic since
  *       insertion only follows an equality-constrained optimum);
  *   C5  blocking step and removal as in AD3 (first index wins ties because of the strict <);
- *   C6  max_iter counts loop passes (solve passes and insert/remove passes alike).
+ *   C6  max_iter counts loop passes (solve passes and insert/remove passes alike);
+ *   C7  the rank-one-updated inverse loses accuracy over long runs of updates and when a nearly
+ *       affinely dependent vertex is inserted (1/s amplifies the rounding of d), and then both
+ *       the distribution (sum p != 1) and the convergence decision are off.  So a would-be
+ *       convergence (value <= tau + 1e-9) is only accepted on an accurate solution of the KKT
+ *       system K [tau; z] = [1; b], K = [[0,1^T],[1,G]], G_ij = common values.  With rho the
+ *       largest |residual| over the rows (serial left-to-right sums, product rounded then added):
+ *         rho <= SM_KKT_TOL (1e-12): accepted as it is;
+ *         rho <= SM_KKT_REBUILD (1e-9): up to SM_KKT_POLISH steps of iterative refinement in
+ *           place, [dtau; dz] = invA^T res, then accepted (no extra pass: the decision was sound);
+ *         rho > SM_KKT_REBUILD, inverse not yet rebuilt for this active set: the inverse is
+ *           recomputed from the active set -- in-place Gauss-Jordan elimination without pivoting,
+ *           pivots in the order configurations 1..m, then the multiplier row 0 (G is positive
+ *           definite for affinely independent vertices, the last pivot is -1/(1^T G^-1 1)); every
+ *           element update is v - c_i * (r_j * piv), three roundings and no sums -- the system is
+ *           solved again and refined, the pass ends (it counts, C6) and the NEXT passes judge the
+ *           fresh solution like any other: blocking test, then optimality.  A sample whose
+ *           convergence was an artefact of the drift goes on iterating (and may end MAXITER).
+ *       Upstream has no such step (its distributions drift the same way); this restatement
+ *       trades bit-for-bit imitation of that for marginals that can be certified: every CONVERGED
+ *       sample has |sum p - 1| <= 1e-14 and marginals within 1e-9 of the closed form.
  */
 #include <math.h>
 #include <stdint.h>
@@ -110,6 +130,66 @@ static int common_values(const uint32_t* a, const uint32_t* b, int n)
     return n - diff;
 }
 
+#define SM_KKT_TOL 1e-12      /* accepted residual of the KKT system (any row) */
+#define SM_KKT_REBUILD 1e-9   /* above this the cached inverse itself is recomputed */
+#define SM_KKT_POLISH 3       /* polishing rounds per active set */
+
+/* C7: res[0..m] = [1; b] - K [tau; z] with K = [[0,1^T],[1,G]], G_ij = common values; every row
+ * a serial left-to-right sum (product rounded, then added).  Returns max_i |res_i|. */
+static double kkt_residual(const double* z, double tau, const double* bvec, const uint32_t* cfg,
+                           int m, int n, double* res)
+{
+    const int W = SM_WORDS(n);
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) acc += z[j];
+    res[0] = 1.0 - acc;
+    double worst = fabs(res[0]);
+    for (int i = 0; i < m; ++i) {
+        double a = tau;
+        for (int j = 0; j < m; ++j) {
+            const double t = (double)common_values(cfg + i * W, cfg + j * W, n) * z[j];
+            a += t;
+        }
+        res[i + 1] = bvec[i + 1] - a;
+        if (fabs(res[i + 1]) > worst) worst = fabs(res[i + 1]);
+    }
+    return worst;
+}
+
+/* C7: A (ld x ld, indices 0..m) := inverse of [[0,1^T],[1,G]] by in-place Gauss-Jordan, pivot
+ * order 1..m, 0; col/row: scratch of m+1 doubles each. */
+static void rebuild_inverse(double* A, int ld, const uint32_t* cfg, int m, int n, double* col,
+                            double* row)
+{
+    const int W = SM_WORDS(n);
+    A[0] = 0.0;
+    for (int i = 1; i <= m; ++i) {
+        A[i] = 1.0;
+        A[i * ld] = 1.0;
+        for (int j = 1; j <= m; ++j)
+            A[i * ld + j] = (double)common_values(cfg + (i - 1) * W, cfg + (j - 1) * W, n);
+    }
+    for (int step = 0; step <= m; ++step) {
+        const int k = step < m ? step + 1 : 0;
+        const double piv = 1.0 / A[k * ld + k];
+        for (int i = 0; i <= m; ++i) { col[i] = A[i * ld + k]; row[i] = A[k * ld + i] * piv; }
+        for (int i = 0; i <= m; ++i) {
+            if (i == k) continue;
+            for (int j = 0; j <= m; ++j) {
+                if (j == k) continue;
+                const double t = col[i] * row[j];
+                A[i * ld + j] = A[i * ld + j] - t;
+            }
+        }
+        for (int i = 0; i <= m; ++i) {
+            if (i == k) continue;
+            A[k * ld + i] = row[i];
+            A[i * ld + k] = -col[i] * piv;
+        }
+        A[k * ld + k] = piv;
+    }
+}
+
 /*
  * scores[B,n] fp32; init_scores[B,2n] fp64 or NULL (torch.rand(2n, dtype=double) per sample,
  * sparsemap.py:25-27); budget 0 => Bernoulli.
@@ -141,6 +221,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
     double* bvec = (double*)malloc(sizeof(double) * (size_t)ld);
     double* r = (double*)malloc(sizeof(double) * (size_t)ld);
     double* d = (double*)malloc(sizeof(double) * (size_t)ld);
+    double* e_res = (double*)malloc(sizeof(double) * (size_t)ld);
     uint32_t* cfg = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap * W);
     uint32_t* newc = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W);
 
@@ -155,7 +236,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
         dist[0] = 1.0;
         A[0 * ld + 0] = -(double)n; A[0 * ld + 1] = 1.0; A[1 * ld + 0] = 1.0; A[1 * ld + 1] = 0.0;
 
-        int changed = 1, st = SM_MAXITER, it;
+        int changed = 1, st = SM_MAXITER, it, rebuilt = 0, refined = 0;
         double tau = 0.0;
         for (it = 0; it < max_iter; ++it) {
             int same = 1;
@@ -173,6 +254,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 }
                 same = 0;
             }
+            if (refined) { refined = 0; same = 0; } /* C7: z was corrected in the last pass */
             if (same) {
                 for (int k = 0; k < n; ++k) { mu_on[k] = 0.0; mu_off[k] = 0.0; }
                 for (int i = 0; i < m; ++i)
@@ -180,7 +262,44 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                         if (bit_of(cfg + i * W, k)) mu_on[k] += z[i]; else mu_off[k] += z[i];
                 for (int k = 0; k < n; ++k) { mu_on[k] = eta[k] - mu_on[k]; mu_off[k] = 0.0 - mu_off[k]; }
                 double value = maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
-                if (value <= tau + 1e-9) { st = SM_CONVERGED; break; }
+                if (value <= tau + 1e-9) {
+                    /* C7: accept only an accurate solution of the KKT system */
+                    double rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                    if (rho > SM_KKT_REBUILD && !rebuilt) {
+                        /* the cached inverse has drifted: recompute it, solve again and let the
+                         * loop judge the fresh solution (blocking test, then optimality) */
+                        rebuild_inverse(A, ld, cfg, m, n, d, e_res);
+                        rebuilt = 1;
+                        for (int c = 0; c <= m; ++c) {
+                            double acc = 0.0;
+                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
+                            if (c == 0) tau = acc; else z[c - 1] = acc;
+                        }
+                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                        for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
+                            for (int c = 0; c <= m; ++c) {
+                                double acc = 0.0;
+                                for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
+                                if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
+                            }
+                            rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                        }
+                        refined = 1;
+                        continue;
+                    }
+                    /* small residual: iterative refinement in place, [dtau; dz] = invA^T res */
+                    for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
+                        for (int c = 0; c <= m; ++c) {
+                            double acc = 0.0;
+                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
+                            if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
+                        }
+                        for (int i = 0; i < m; ++i) dist[i] = z[i];
+                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                    }
+                    st = SM_CONVERGED;
+                    break;
+                }
                 int dup = 0;
                 for (int i = 0; i < m && !dup; ++i) dup = (memcmp(cfg + i * W, newc, sizeof(uint32_t) * W) == 0);
                 if (dup) { st = SM_DUPLICATE; break; }
@@ -209,6 +328,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 memcpy(cfg + m * W, newc, sizeof(uint32_t) * W);
                 ++m;
                 changed = 1;
+                rebuilt = 0;
             } else {
                 int blocking = -1, exist = 0;
                 double alpha = 1.0;
@@ -256,6 +376,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                     }
                     --m;
                     changed = 1;
+                    rebuilt = 0;
                 }
             }
         }
@@ -276,7 +397,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
         if (status) status[s_] = st;
     }
     free(eta); free(zero); free(mu_on); free(mu_off); free(e_tmp); free(idx_tmp); free(A); free(A2);
-    free(z); free(dist); free(bvec); free(r); free(d); free(cfg); free(newc);
+    free(z); free(dist); free(bvec); free(r); free(d); free(e_res); free(cfg); free(newc);
     return 0;
 }
 

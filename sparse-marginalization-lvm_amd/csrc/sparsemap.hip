@@ -372,6 +372,104 @@ struct Sm {
     }
 };
 
+// ---- C7 of oracle/sparsemap_oracle.c: a convergence is only accepted on an accurate KKT solution
+constexpr double kKktTol = 1e-12;      // accepted residual (any row)
+constexpr double kKktRebuild = 1e-9;   // above this the cached inverse is recomputed from the active set
+constexpr int kKktPolish = 3;          // refinement steps
+
+// res = [1; b] - K [tau; z], K = [[0,1^T],[1,G]], G_ij = common values of configurations i, j.
+// Lane i + 64 q owns row i + 64 q: a serial left-to-right sum over j (product rounded, then
+// added), exactly the oracle's kkt_residual.  res goes to r[] (zero beyond m: it is the right-hand
+// side of the refinement's matvec).  Returns max_i |res_i|, the same bits in every lane.
+template <int WT, int NA>
+__device__ __forceinline__ double kkt_residual(const double* z, double tau, const double* bsc,
+                                               const uint32_t* cfg, int m, int n, double* r, int lane)
+{
+    double worst = 0.0;
+#pragma unroll
+    for (int q = 0; q * 64 < NA; ++q) {
+        const int i = lane + 64 * q;
+        if (q * 64 <= m && i < NA) {
+            double res = 0.0;
+            if (i == 0) {
+                double acc = 0.0;
+                for (int j = 0; j < m; ++j) acc += z[j];
+                res = 1.0 - acc;
+            } else if (i <= m) {
+                uint32_t ci[WT];
+#pragma unroll
+                for (int w = 0; w < WT; ++w) ci[w] = cfg[(i - 1) * WT + w];
+                double a = tau;
+                for (int j = 0; j < m; ++j) {
+                    int diff = 0;
+#pragma unroll
+                    for (int w = 0; w < WT; ++w) diff += __popc(ci[w] ^ cfg[j * WT + w]);
+                    const double t = (double)(n - diff) * z[j];
+                    a += t;
+                }
+                res = bsc[i] - a;
+            }
+            r[i] = res;
+            worst = fmax(worst, fabs(res));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, bcast_f64(worst, lane ^ o));
+    wsync();
+    return uni(worst);
+}
+
+// A (indices 0..m) := K^-1 by in-place Gauss-Jordan elimination without pivoting, pivots in the
+// order 1..m, 0 (the oracle's rebuild_inverse).  Every element update is v - c_i * (r_j * piv):
+// element-wise, no sums, so the lanes (one column each) produce the oracle's bits.  colv / rowv:
+// LDS scratch of m + 1 doubles each.
+template <int LD, int WT>
+__device__ __forceinline__ void rebuild_inverse(double* A, const uint32_t* cfg, int m, int n,
+                                                double* colv, double* rowv, int lane)
+{
+    for (int i = 0; i <= m; ++i) {
+        for (int j = lane; j <= m; j += 64) {
+            double v;
+            if (i == 0) v = (j == 0) ? 0.0 : 1.0;
+            else if (j == 0) v = 1.0;
+            else {
+                int diff = 0;
+#pragma unroll
+                for (int w = 0; w < WT; ++w) diff += __popc(cfg[(i - 1) * WT + w] ^ cfg[(j - 1) * WT + w]);
+                v = (double)(n - diff);
+            }
+            A[i * LD + j] = v;
+        }
+    }
+    wsync();
+    for (int step = 0; step <= m; ++step) {
+        const int k = step < m ? step + 1 : 0;
+        const double piv = uni(1.0 / A[k * LD + k]);
+        for (int i = lane; i <= m; i += 64) {
+            colv[i] = A[i * LD + k];
+            rowv[i] = A[k * LD + i] * piv;
+        }
+        wsync();
+        for (int j = lane; j <= m; j += 64) {
+            if (j == k) continue;
+            const double rj = rowv[j];
+            for (int i = 0; i <= m; ++i) {
+                if (i == k) continue;
+                const double t = colv[i] * rj;
+                A[i * LD + j] = A[i * LD + j] - t;
+            }
+        }
+        wsync();
+        for (int i = lane; i <= m; i += 64) {
+            if (i == k) continue;
+            A[k * LD + i] = rowv[i];
+            A[i * LD + k] = -colv[i] * piv;
+        }
+        if (lane == 0) A[k * LD + k] = piv;
+        wsync();
+    }
+}
+
 template <int LD, int WT, int NK>
 __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     const float* __restrict__ scores, const double* __restrict__ init_scores, int budget,
@@ -466,27 +564,36 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     SM_T0();
     int st = SM_MAXITER;
     bool overflow = false;
+    bool rebuilt = false, refined = false;   // C7 (never set when a sample is parked: see below)
+    // [tau; z] (+)= invA^T rhs: lane c owns output c, serial in j like the oracle
+    auto kkt_apply = [&](const double* rhs, bool accumulate) {
+        const int cnt8 = round8(m + 1);
+        double t0 = 0.0;
+#pragma unroll
+        for (int q = 0; q * 64 < L::NA; ++q) {
+            const int c = lane + 64 * q;
+            if (q * 64 <= cnt8) {   // uniform: chunks that hold an output or padding to clear
+                const int cc = c < LD ? c : LD - 1;
+                const double acc = matvec_col<LD>(A + cc, rhs, cnt8);
+                if (c == 0) t0 = acc;
+                else if (c - 1 < L::NA) {
+                    if (accumulate) { if (c <= m) z[c - 1] = z[c - 1] + acc; }
+                    else z[c - 1] = (c <= m) ? acc : 0.0;
+                }
+            }
+        }
+        tau = accumulate ? uni(tau + t0) : uni(t0);
+        wsync();
+    };
     for (; it < max_iter; ++it) {
         bool same = true;
         if (changed) {
             // [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)]
-            const int cnt8 = round8(m + 1);
-            double t0 = 0.0;
-#pragma unroll
-            for (int q = 0; q * 64 < L::NA; ++q) {
-                const int c = lane + 64 * q;
-                if (q * 64 <= cnt8) {   // uniform: chunks that hold an output or padding to clear
-                    const int cc = c < LD ? c : LD - 1;
-                    const double acc = matvec_col<LD>(A + cc, bsc, cnt8);
-                    if (c == 0) t0 = acc;
-                    else if (c - 1 < L::NA) z[c - 1] = (c <= m) ? acc : 0.0;
-                }
-            }
-            tau = uni(t0);
+            kkt_apply(bsc, false);
             same = false;
-            wsync();
             SM_T(0);
         }
+        if (refined) { refined = false; same = false; }   // C7: z was re-solved in the last pass
         if (same) {
             double mon[NK], moff[NK];
             marginals<WT, NK>(cfg, z, round8(m), lane, mon, moff);
@@ -499,7 +606,33 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             double value, evalsum;
             S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
-            if (uni(value <= tau + 1e-9)) { st = SM_CONVERGED; break; }
+            if (uni(value <= tau + 1e-9)) {
+                // C7: accept only an accurate solution of the KKT system
+                double rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                if (rho > kKktRebuild && !rebuilt) {
+                    // the cached inverse has drifted: recompute it, solve again, and let the next
+                    // passes judge the fresh solution (blocking test, then optimality)
+                    rebuild_inverse<LD, WT>(A, cfg, m, n, d, t1, lane);
+                    rebuilt = true;
+                    kkt_apply(bsc, false);
+                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                    for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
+                        kkt_apply(r, true);
+                        rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                    }
+                    refined = true;
+                    continue;
+                }
+                // small residual: iterative refinement in place
+                for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
+                    kkt_apply(r, true);
+                    for (int i = lane; i < m; i += 64) dist[i] = z[i];
+                    wsync();
+                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                }
+                st = SM_CONVERGED;
+                break;
+            }
             // SameConfiguration against every active entry + r = [1; CountCommonValues(cfg_i, new)]
             bool dup = false;
 #pragma unroll
@@ -609,6 +742,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             if (lane < WT) cfg[m * WT + lane] = newc[lane];
             ++m;
             changed = true;
+            rebuilt = false;
             wsync();
             SM_T(6);
         } else {
@@ -710,6 +844,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 }
                 --m;
                 changed = true;
+                rebuilt = false;
                 wsync();
                 SM_T(9);
             }

@@ -119,27 +119,49 @@ def test_max_iter_is_respected(dev, oracle_mod):
         assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
 
 
-def test_marginals_closed_form_full_size(dev):
-    """cfg5 shape (1024 samples/GPU at 128 bits): M p equals the closed-form marginals."""
+@pytest.mark.parametrize("sigma,budget", [(3.0, 0), (1.0, 0), (3.0, 64)])
+def test_marginals_closed_form_full_size(dev, oracle_mod, sigma, budget):
+    """cfg5 shape (1024 samples/GPU at 128 bits): for EVERY converged sample M p equals the
+    closed-form marginals and sum p = 1 to the precision of the fp32 output (1e-6) -- the solver
+    only accepts a convergence on an accurate solution of the KKT system (C7 of the oracle:
+    residual check, inverse rebuilt from the active set when it has drifted, iterative refinement).
+    A slice of the batch is compared with the fp64 oracle bit for bit, where the same holds to 1e-9."""
     from lvmhelpers import _native
     B, n = 1024, 128
     g = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(B, n, device=dev, generator=g) * 3
-    init = torch.rand(B, 2 * n, dtype=torch.double).to(dev)
-    out = _native.sparsemap_fwd(x, init, 0, 300)
-    ok = out["status"] == 0  # converged by the KKT test (value <= tau + 1e-9)
-    assert ok.float().mean() > 0.9
+    x = torch.randn(B, n, device=dev, generator=g) * sigma
+    init = torch.rand(B, 2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(3)).to(dev)
+    out = _native.sparsemap_fwd(x, init, budget, 300)
+    ok = out["status"] == 0  # converged by the KKT test (value <= tau + 1e-9) on an accurate solution
+    assert ok.float().mean() > 0.8
     k = torch.arange(n, device=dev)
     bits = ((out["aset_bits"][..., k // 32] >> (k % 32)) & 1).double()     # [B,cap,n]
     mu = torch.einsum("bc,bcn->bn", out["p"].double(), bits)
-    mu_ref = ((x.double() + 1) / 2).clamp(0, 1)
-    err = (mu - mu_ref).abs().max(dim=-1)[0]
     psum = (out["p"].double().sum(-1) - 1).abs()
-    # The published active-set method keeps a rank-one-updated inverse; near convergence it can
-    # insert an almost affinely dependent vertex (|s| barely above its 1e-9 test) and lose the
-    # inverse.  That is a property of the algorithm (the CPU oracle does the same, bit for bit),
-    # seen on a few % of samples at 128 bits with |scores| ~ 3; everything else is at the optimum.
-    good = ok & (psum < 1e-6)
-    assert good.float().mean() > 0.95
-    assert err[good].max() < 1e-4
-    assert torch.all(out["p"][good] >= -1e-7)
+    assert float(psum[ok].max()) <= 1e-6
+    assert bool((out["p"][ok] >= 0).all()) or float(out["p"][ok].min()) > -1e-9
+    if budget == 0:
+        mu_ref = ((x.double() + 1) / 2).clamp(0, 1)
+        err = (mu - mu_ref).abs().max(dim=-1)[0]
+        assert float(err[ok].max()) <= 1e-6
+    else:
+        assert bool((bits.sum(-1)[out["p"] > 0] <= budget).all())
+    # the first 96 samples against the oracle: identical, and accurate to 1e-9 in fp64 there
+    nb = 96
+    ref = oracle_mod.sparsemap_fwd(x[:nb].cpu().numpy(), init[:nb].cpu().numpy(), budget, 300)
+    assert np.array_equal(out["status"][:nb].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["iters"][:nb].cpu().numpy(), ref["iters"])
+    assert np.array_equal(out["alen"][:nb].cpu().numpy(), ref["alen"])
+    assert np.array_equal(out["p"][:nb].cpu().numpy(), ref["p"])
+    assert np.array_equal(out["aset_bits"][:nb].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    inv = out["inv_a"][:nb].cpu().numpy()
+    for b in range(nb):
+        m = ref["alen"][b]
+        assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
+    okr = ref["status"] == 0
+    assert np.abs(ref["p64"].sum(-1) - 1)[okr].max() <= 1e-12
+    if budget == 0:
+        bits_r = oracle_mod.unpack_bits(ref["aset_bits"], n).astype(np.float64)
+        mu_r = np.einsum("bc,bcn->bn", ref["p64"], bits_r)
+        mu_c = np.clip((x[:nb].cpu().numpy().astype(np.float64) + 1) / 2, 0, 1)
+        assert np.abs(mu_r - mu_c)[okr].max() <= 1e-9

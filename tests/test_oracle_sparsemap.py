@@ -73,6 +73,31 @@ def test_budget_marginals(n, budget):
     assert np.abs(mu - _budget_projection(x, budget))[ok].max() < 1e-5
 
 
+@pytest.mark.parametrize("sigma,budget", [(3.0, 0), (1.0, 0), (1.0, 64)])
+def test_every_converged_sample_is_accurate_at_128_bits(sigma, budget):
+    """C7 of the oracle: at 128 bits the rank-one-updated inverse used to drift (sum p off by up to
+    4e-2 at sigma = 3, false convergences); a convergence is now only accepted on an accurate KKT
+    solution, so EVERY converged sample has sum p = 1 to 1e-12 and the closed-form marginals to 1e-9."""
+    B, n = 256, 128
+    x, init = _problem(B, n, sigma, 77)
+    o = oracle.sparsemap_fwd(x, init, budget, 300)
+    ok = o["status"] == 0
+    assert ok.mean() > 0.8
+    assert np.abs(o["p64"].sum(-1) - 1)[ok].max() <= 1e-12
+    assert o["p64"][ok].min() >= -1e-12
+    mu, bits = _marginals(o, n)
+    if budget == 0:
+        assert np.abs(mu - np.clip((x.astype(np.float64) + 1) / 2, 0, 1))[ok].max() <= 1e-9
+    else:
+        assert np.all(bits.sum(-1)[o["p64"] > 0] <= budget)
+        assert np.abs(mu - _budget_projection(x, budget))[ok].max() <= 1e-7   # bisection reference
+    for b in np.nonzero(ok)[0][:40]:                     # the cached inverse really is the inverse
+        m = o["alen"][b]
+        M = np.concatenate([bits[b, :m], 1 - bits[b, :m]], 1)
+        A = np.zeros((m + 1, m + 1)); A[0, 1:] = 1; A[1:, 0] = 1; A[1:, 1:] = M @ M.T
+        assert np.abs(o["invA"][b, :m + 1, :m + 1] @ A - np.eye(m + 1)).max() < 1e-6
+
+
 def test_vertex_solution_without_init():                                                    # (vi)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((16, 24)).astype(np.float32)
