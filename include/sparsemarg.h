@@ -161,7 +161,10 @@ int smlvm_binary_topk_batched(const float* scores, float* configs, float* topsco
  *   alen      [B] int32            len(aset)
  *   inv_a     [B, ld, ld] fp64     cached inverse KKT matrix (rows/cols 0..alen[b] written); the
  *                                  state the reference keeps on ctx.f between forward and backward
- *   iters     [B] int32, status [B] int32 (0 converged, 1 max_iter, 2 singular, 3 duplicate); nullable
+ *   iters     [B] int32, status [B] int32 (0 converged, 1 max_iter, 2 singular, 3 duplicate,
+ *                                  4 stalled: no accurate KKT solution within the polishing budget,
+ *                                  see oracle/sparsemap_oracle.c C7); nullable.  A converged sample has
+ *                                  sum p = 1 and the optimal marginals to the precision of the fp32 output
  *   workspace : smlvm_sparsemap_fwd_workspace_bytes(B, n, inv_a != NULL) bytes, 8-byte aligned
  *               (0 for n <= 64: may be NULL).  For n > 64 the batch runs in tiers of growing LDS
  *               footprint (4, 2, 1 samples per CU); a sample whose active set outgrows a tier parks

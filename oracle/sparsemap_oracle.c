@@ -40,20 +40,28 @@
  *       convergence (value <= tau + 1e-9) is only accepted on an accurate solution of the KKT
  *       system K [tau; z] = [1; b], K = [[0,1^T],[1,G]], G_ij = common values.  With rho the
  *       largest |residual| over the rows (serial left-to-right sums, product rounded then added):
- *         rho <= SM_KKT_TOL (1e-12): accepted as it is;
- *         rho <= SM_KKT_REBUILD (1e-9): up to SM_KKT_POLISH steps of iterative refinement in
- *           place, [dtau; dz] = invA^T res, then accepted (no extra pass: the decision was sound);
- *         rho > SM_KKT_REBUILD, inverse not yet rebuilt for this active set: the inverse is
- *           recomputed from the active set -- in-place Gauss-Jordan elimination without pivoting,
- *           pivots in the order configurations 1..m, then the multiplier row 0 (G is positive
- *           definite for affinely independent vertices, the last pivot is -1/(1^T G^-1 1)); every
- *           element update is v - c_i * (r_j * piv), three roundings and no sums -- the system is
- *           solved again and refined, the pass ends (it counts, C6) and the NEXT passes judge the
- *           fresh solution like any other: blocking test, then optimality.  A sample whose
- *           convergence was an artefact of the drift goes on iterating (and may end MAXITER).
- *       Upstream has no such step (its distributions drift the same way); this restatement
- *       trades bit-for-bit imitation of that for marginals that can be certified: every CONVERGED
- *       sample has |sum p - 1| <= 1e-14 and marginals within 1e-9 of the closed form.
+ *         - while rho > SM_KKT_TOL (1e-10), up to SM_KKT_POLISH steps of iterative refinement,
+ *           [dtau; dz] = invA^T res (the cached inverse as the approximate solver);
+ *         - if that does not get there (the inverse has drifted by several per cent) and the
+ *           sample has a rebuild left (SM_KKT_MAX_REBUILDS), it is recomputed from the active set --
+ *           in-place Gauss-Jordan elimination without pivoting, pivots in the order
+ *           configurations 1..m, then the multiplier row 0 (G is positive definite for affinely
+ *           independent vertices, the last pivot is -1/(1^T G^-1 1)); every element update is
+ *           v - c_i * (r_j * piv), three roundings and no sums -- the system is solved again and
+ *           refined;
+ *         - if the residual it started from was above SM_KKT_REJUDGE (1e-8: ten times the
+ *           tolerance of the convergence test) the decision was not sound: the pass ends (it
+ *           counts, C6) and the NEXT passes judge the polished solution like any other --
+ *           blocking test, then optimality (once per active set, SM_KKT_MAX_REJUDGES times per
+ *           sample; a sample that would need more, or that has not converged SM_KKT_PATIENCE
+ *           passes after a re-judgement -- those that do converge take under 50 -- ends with
+ *           status STALLED and its last feasible distribution: its active sets are too
+ *           ill-conditioned for this method in fp64);
+ *           otherwise the polished solution is the result.
+ *       Upstream has no such step (its distributions drift the same way and some of its
+ *       convergences are artefacts of the drift); this restatement trades bit-for-bit imitation
+ *       of that for results that can be certified: every CONVERGED sample has |sum p - 1| <= 1e-9
+ *       (1e-12 in practice) and marginals within 1e-9 of the closed form.
  */
 #include <math.h>
 #include <stdint.h>
@@ -63,7 +71,7 @@
 #define SM_MAX_N 512
 #define SM_WORDS(n) (((n) + 31) / 32)
 
-enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3 };
+enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3, SM_STALLED = 4 };
 
 static inline int bit_of(const uint32_t* cfg, int k) { return (cfg[k >> 5] >> (k & 31)) & 1u; }
 
@@ -130,9 +138,12 @@ static int common_values(const uint32_t* a, const uint32_t* b, int n)
     return n - diff;
 }
 
-#define SM_KKT_TOL 1e-12      /* accepted residual of the KKT system (any row) */
-#define SM_KKT_REBUILD 1e-9   /* above this the cached inverse itself is recomputed */
-#define SM_KKT_POLISH 3       /* polishing rounds per active set */
+#define SM_KKT_TOL 1e-10      /* accepted residual of the KKT system (any row) */
+#define SM_KKT_MAX_REJUDGES 2  /* re-judgements per sample */
+#define SM_KKT_PATIENCE 64     /* passes a re-judged sample gets to converge */
+#define SM_KKT_REJUDGE 1e-8   /* a starting residual above this voids the convergence decision */
+#define SM_KKT_POLISH 2       /* refinement steps per attempt */
+#define SM_KKT_MAX_REBUILDS 1 /* recomputations of the inverse per sample */
 
 /* C7: res[0..m] = [1; b] - K [tau; z] with K = [[0,1^T],[1,G]], G_ij = common values; every row
  * a serial left-to-right sum (product rounded, then added).  Returns max_i |res_i|. */
@@ -236,10 +247,11 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
         dist[0] = 1.0;
         A[0 * ld + 0] = -(double)n; A[0 * ld + 1] = 1.0; A[1 * ld + 0] = 1.0; A[1 * ld + 1] = 0.0;
 
-        int changed = 1, st = SM_MAXITER, it, rebuilt = 0, refined = 0;
+        int changed = 1, st = SM_MAXITER, it, judged = 0, refined = 0, rebuilds = 0, rejudges = 0, last_rejudge = 0;
         double tau = 0.0;
         for (it = 0; it < max_iter; ++it) {
             int same = 1;
+            if (rejudges > 0 && it - last_rejudge > SM_KKT_PATIENCE) { st = SM_STALLED; break; } /* C7 */
             if (changed) {
                 bvec[0] = 1.0;
                 for (int i = 0; i < m; ++i) { /* Evaluate under eta = [x; 0] */
@@ -264,12 +276,20 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 double value = maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
                 if (value <= tau + 1e-9) {
                     /* C7: accept only an accurate solution of the KKT system */
-                    double rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                    if (rho > SM_KKT_REBUILD && !rebuilt) {
-                        /* the cached inverse has drifted: recompute it, solve again and let the
-                         * loop judge the fresh solution (blocking test, then optimality) */
+                    const double rho0 = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                    double rho = rho0;
+                    for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
+                        for (int c = 0; c <= m; ++c) { /* [dtau; dz] = invA^T res */
+                            double acc = 0.0;
+                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
+                            if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
+                        }
+                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
+                    }
+                    if (rho > SM_KKT_TOL && rebuilds < SM_KKT_MAX_REBUILDS) {
+                        /* the cached inverse is too far off for the refinement to converge */
                         rebuild_inverse(A, ld, cfg, m, n, d, e_res);
-                        rebuilt = 1;
+                        ++rebuilds;
                         for (int c = 0; c <= m; ++c) {
                             double acc = 0.0;
                             for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
@@ -284,19 +304,18 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                             }
                             rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
                         }
+                    }
+                    if (rho0 > SM_KKT_REJUDGE && !judged) {
+                        if (rejudges >= SM_KKT_MAX_REJUDGES) { st = SM_STALLED; break; }
+                        ++rejudges;
+                        last_rejudge = it;
+                        /* the solution moved by more than the convergence tolerance: the next
+                         * passes judge the polished one (blocking test, then optimality) */
+                        judged = 1;
                         refined = 1;
                         continue;
                     }
-                    /* small residual: iterative refinement in place, [dtau; dz] = invA^T res */
-                    for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
-                        for (int c = 0; c <= m; ++c) {
-                            double acc = 0.0;
-                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
-                            if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
-                        }
-                        for (int i = 0; i < m; ++i) dist[i] = z[i];
-                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                    }
+                    for (int i = 0; i < m; ++i) dist[i] = z[i];
                     st = SM_CONVERGED;
                     break;
                 }
@@ -328,7 +347,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 memcpy(cfg + m * W, newc, sizeof(uint32_t) * W);
                 ++m;
                 changed = 1;
-                rebuilt = 0;
+                judged = 0;
             } else {
                 int blocking = -1, exist = 0;
                 double alpha = 1.0;
@@ -376,7 +395,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                     }
                     --m;
                     changed = 1;
-                    rebuilt = 0;
+                    judged = 0;
                 }
             }
         }

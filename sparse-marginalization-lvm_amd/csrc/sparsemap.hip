@@ -32,7 +32,7 @@
 
 namespace smlvm {
 
-enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3 };
+enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3, SM_STALLED = 4 };
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
@@ -373,9 +373,15 @@ struct Sm {
 };
 
 // ---- C7 of oracle/sparsemap_oracle.c: a convergence is only accepted on an accurate KKT solution
-constexpr double kKktTol = 1e-12;      // accepted residual (any row)
-constexpr double kKktRebuild = 1e-9;   // above this the cached inverse is recomputed from the active set
-constexpr int kKktPolish = 3;          // refinement steps
+constexpr double kKktTol = 1e-10;      // accepted residual (any row)
+constexpr double kKktRejudge = 1e-8;   // a starting residual above this voids the convergence decision
+constexpr int kKktPolish = 2;          // refinement steps per attempt
+#ifndef SMLVM_EXP_MAXREB
+#define SMLVM_EXP_MAXREB 1
+#endif
+constexpr int kKktMaxRebuilds = SMLVM_EXP_MAXREB;     // recomputations of the inverse per sample
+constexpr int kKktMaxRejudges = 2;     // re-judgements per sample
+constexpr int kKktPatience = 64;       // passes a re-judged sample gets to converge
 
 // res = [1; b] - K [tau; z], K = [[0,1^T],[1,G]], G_ij = common values of configurations i, j.
 // Lane i + 64 q owns row i + 64 q: a serial left-to-right sum over j (product rounded, then
@@ -385,6 +391,10 @@ template <int WT, int NA>
 __device__ __forceinline__ double kkt_residual(const double* z, double tau, const double* bsc,
                                                const uint32_t* cfg, int m, int n, double* r, int lane)
 {
+    // z is zero beyond m and the configuration rows beyond m hold finite words, so the serial sums
+    // run over round8(m) terms in 8-step batches (a + 0.0 == a) with the operands of a batch
+    // fetched together; the additions themselves stay strictly left to right.
+    const int m8 = round8(m);
     double worst = 0.0;
 #pragma unroll
     for (int q = 0; q * 64 < NA; ++q) {
@@ -393,19 +403,30 @@ __device__ __forceinline__ double kkt_residual(const double* z, double tau, cons
             double res = 0.0;
             if (i == 0) {
                 double acc = 0.0;
-                for (int j = 0; j < m; ++j) acc += z[j];
+                for (int j0 = 0; j0 < m8; j0 += 8) {
+                    double zz[8];
+                    ld8(z + j0, zz);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += zz[u];
+                }
                 res = 1.0 - acc;
             } else if (i <= m) {
                 uint32_t ci[WT];
 #pragma unroll
                 for (int w = 0; w < WT; ++w) ci[w] = cfg[(i - 1) * WT + w];
                 double a = tau;
-                for (int j = 0; j < m; ++j) {
-                    int diff = 0;
+                for (int j0 = 0; j0 < m8; j0 += 8) {
+                    double zz[8], t[8];
+                    ld8(z + j0, zz);
 #pragma unroll
-                    for (int w = 0; w < WT; ++w) diff += __popc(ci[w] ^ cfg[j * WT + w]);
-                    const double t = (double)(n - diff) * z[j];
-                    a += t;
+                    for (int u = 0; u < 8; ++u) {
+                        int diff = 0;
+#pragma unroll
+                        for (int w = 0; w < WT; ++w) diff += __popc(ci[w] ^ cfg[(j0 + u) * WT + w]);
+                        t[u] = (double)(n - diff) * zz[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a += t[u];
                 }
                 res = bsc[i] - a;
             }
@@ -422,7 +443,7 @@ __device__ __forceinline__ double kkt_residual(const double* z, double tau, cons
 // A (indices 0..m) := K^-1 by in-place Gauss-Jordan elimination without pivoting, pivots in the
 // order 1..m, 0 (the oracle's rebuild_inverse).  Every element update is v - c_i * (r_j * piv):
 // element-wise, no sums, so the lanes (one column each) produce the oracle's bits.  colv / rowv:
-// LDS scratch of m + 1 doubles each.
+// LDS scratch of round8(m + 1) doubles each.
 template <int LD, int WT>
 __device__ __forceinline__ void rebuild_inverse(double* A, const uint32_t* cfg, int m, int n,
                                                 double* colv, double* rowv, int lane)
@@ -442,21 +463,31 @@ __device__ __forceinline__ void rebuild_inverse(double* A, const uint32_t* cfg, 
         }
     }
     wsync();
+    const int m8 = round8(m + 1);
     for (int step = 0; step <= m; ++step) {
         const int k = step < m ? step + 1 : 0;
         const double piv = uni(1.0 / A[k * LD + k]);
-        for (int i = lane; i <= m; i += 64) {
-            colv[i] = A[i * LD + k];
-            rowv[i] = A[k * LD + i] * piv;
+        // column k and the scaled row k; colv gets zeros at k and in the padding, so that the
+        // update below needs no conditions (v - 0 * r_j == v) and runs in 8-row batches
+        for (int i = lane; i < m8; i += 64) {
+            const bool in = i <= m;
+            colv[i] = (in && i != k) ? A[i * LD + k] : 0.0;
+            rowv[i] = in ? A[k * LD + i] * piv : 0.0;
         }
         wsync();
         for (int j = lane; j <= m; j += 64) {
             if (j == k) continue;
             const double rj = rowv[j];
-            for (int i = 0; i <= m; ++i) {
-                if (i == k) continue;
-                const double t = colv[i] * rj;
-                A[i * LD + j] = A[i * LD + j] - t;
+            double* col = A + j;
+            for (int i0 = 0; i0 < m8; i0 += 8) {   // rows up to m8 - 1 < LDR exist (stale, finite)
+                double a[8], c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = col[(i0 + u) * LD];
+                ld8(colv + i0, c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const double t = c[u] * rj; a[u] = a[u] - t; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) col[(i0 + u) * LD] = a[u];
             }
         }
         wsync();
@@ -492,7 +523,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     const int lane = threadIdx.x;
     const int64_t s = blockIdx.x;
     const int cap = n + 1, W = S.W, ldo = n + 2;
-    if (resume && ws_state[s] != 1) return;   // whole wave: finished in an earlier tier
+    if (resume && (ws_state[s] & 1) == 0) return;   // whole wave: finished in an earlier tier
     double* A = S.A();
     double* z = S.z();
     double* dist = S.dist();
@@ -528,7 +559,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         }
     }
     wsync();
-    int m = 1, it = 0;
+    int m = 1, it = 0, rebuilds = 0, rejudges = 0, last_rejudge = 0;
     bool changed = true;
     double tau = 0.0;
     if (!resume) {
@@ -544,6 +575,9 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     } else {
         m = uni(alen[s]);
         it = uni(ws_it[s]);
+        rebuilds = uni((ws_state[s] >> 4) & 15);
+        rejudges = uni((ws_state[s] >> 8) & 15);
+        last_rejudge = uni(ws_state[s] >> 12);
         tau = uni(ws_tau[s]);
         changed = false;   // parked at the top of an insertion pass
         const double* ai = a_out + s * (int64_t)ldo * ldo;
@@ -564,7 +598,9 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     SM_T0();
     int st = SM_MAXITER;
     bool overflow = false;
-    bool rebuilt = false, refined = false;   // C7 (never set when a sample is parked: see below)
+    // C7: judged / refined are never set when a sample is parked (that happens in an insertion
+    // pass, which clears them); the rebuild / re-judgement counts travel in ws_state
+    bool judged = false, refined = false;
     // [tau; z] (+)= invA^T rhs: lane c owns output c, serial in j like the oracle
     auto kkt_apply = [&](const double* rhs, bool accumulate) {
         const int cnt8 = round8(m + 1);
@@ -587,6 +623,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     };
     for (; it < max_iter; ++it) {
         bool same = true;
+        if (rejudges > 0 && it - last_rejudge > kKktPatience) { st = SM_STALLED; break; }   // C7
         if (changed) {
             // [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)]
             kkt_apply(bsc, false);
@@ -607,29 +644,42 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
             if (uni(value <= tau + 1e-9)) {
+#ifdef SMLVM_EXP_NOC7
+                st = SM_CONVERGED;
+                break;
+#endif
                 // C7: accept only an accurate solution of the KKT system
-                double rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                if (rho > kKktRebuild && !rebuilt) {
-                    // the cached inverse has drifted: recompute it, solve again, and let the next
-                    // passes judge the fresh solution (blocking test, then optimality)
+                const double rho0 = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                double rho = rho0;
+                for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
+                    kkt_apply(r, true);   // iterative refinement: [dtau; dz] = invA^T res
+                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+                }
+                if (rho > kKktTol && rebuilds < kKktMaxRebuilds) {
+                    // the cached inverse is too far off for the refinement to converge
                     rebuild_inverse<LD, WT>(A, cfg, m, n, d, t1, lane);
-                    rebuilt = true;
+                    ++rebuilds;
                     kkt_apply(bsc, false);
                     rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
                     for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
                         kkt_apply(r, true);
                         rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
                     }
+                }
+                if (rho0 > kKktRejudge && !judged) {
+                    // the solution moved by more than the convergence tolerance: the next passes
+                    // judge the polished one (blocking test, then optimality)
+                    if (rejudges >= kKktMaxRejudges) { st = SM_STALLED; break; }
+                    ++rejudges;
+                    last_rejudge = it;
+                    judged = true;
                     refined = true;
+                    SM_T(7);
                     continue;
                 }
-                // small residual: iterative refinement in place
-                for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
-                    kkt_apply(r, true);
-                    for (int i = lane; i < m; i += 64) dist[i] = z[i];
-                    wsync();
-                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                }
+                for (int i = lane; i < m; i += 64) dist[i] = z[i];
+                wsync();
+                SM_T(7);
                 st = SM_CONVERGED;
                 break;
             }
@@ -742,7 +792,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             if (lane < WT) cfg[m * WT + lane] = newc[lane];
             ++m;
             changed = true;
-            rebuilt = false;
+            judged = false;
             wsync();
             SM_T(6);
         } else {
@@ -844,7 +894,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 }
                 --m;
                 changed = true;
-                rebuilt = false;
+                judged = false;
                 wsync();
                 SM_T(9);
             }
@@ -875,7 +925,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         if (iters) iters[s] = it;
         if (status) status[s] = st;
         if (ws_state) {
-            ws_state[s] = overflow ? 1 : 0;
+            ws_state[s] = overflow ? (1 | (rebuilds << 4) | (rejudges << 8) | (last_rejudge << 12)) : 0;
             ws_it[s] = it;
             ws_tau[s] = tau;
         }

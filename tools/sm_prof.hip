@@ -45,7 +45,7 @@ int main(int argc, char** argv)
 #ifndef SMLVM_SM_PROF
         continue;
 #endif
-        const char* names[] = {"solve z", "marginals", "maximize+eval", "dup+r+push", "d=invA r", "sden+t1", "A update+append", "-", "blocking(no)", "blocking+removal"};
+        const char* names[] = {"solve z", "marginals", "maximize+eval", "dup+r+push", "d=invA r", "sden+t1", "A update+append", "C7 polish", "blocking(no)", "blocking+removal"};
         unsigned long long sum = 0; for (int k = 0; k < 10; ++k) sum += prof[k];
         for (int k = 0; k < 10; ++k) printf("  %-18s %12llu ticks  %5.1f%%\n", names[k], prof[k], 100.0 * prof[k] / sum);
         printf("  ticks per iter: %.0f (clock64 = 100 MHz wall clock on gfx9?)\n", (double)sum / tot);
