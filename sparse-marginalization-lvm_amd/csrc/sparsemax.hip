@@ -24,6 +24,14 @@
 
 namespace smlvm {
 
+// Wave number inside the workgroup as a scalar: LDS addresses derived from it stay out of the VGPRs.
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// A float every lane computes identically (from kernel arguments), parked in a scalar register.
+__device__ __forceinline__ float uniform(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 // ------------------------------------------------------------------------------- reducers
 // A reducer combines per-lane partials over everything that holds one row.  `cs` and `edge`
 // reduce several values in ONE step: for the workgroup reducer that is one barrier, and it keeps
@@ -67,6 +75,13 @@ struct BlockRed {
     __device__ __forceinline__ BlockRed(unsigned long long* lds) : base(lds), phase(0) {}
     __device__ __forceinline__ int idx() const { return (int)threadIdx.x; }
     __device__ __forceinline__ int stride() const { return 64 * NW; }
+    // slot index of lane's record, recomputed where it is used (kept alive across the row loop it
+    // would be spilled, and every reduction would start with a scratch reload)
+    static __device__ __forceinline__ int rec_of(int lane)
+    {
+        asm volatile("" : "+v"(lane));
+        return lane * kSlots;
+    }
     __device__ __forceinline__ unsigned long long* next_set()
     {
         unsigned long long* s = base + phase * NW * kSlots;
@@ -101,10 +116,10 @@ struct BlockRed {
         v = group_reduce<64>(v, op);
         unsigned long long* s = next_set();
         const int lane = threadIdx.x & 63;
-        if (lane == 0) s[(threadIdx.x >> 6) * kSlots] = pack(v);
+        if (lane == 0) s[wave_index() * kSlots] = pack(v);
         __syncthreads();
         T part = identity;
-        if (lane < NW) part = unpack<T>(s[lane * kSlots]);
+        if (lane < NW) part = unpack<T>(s[rec_of(lane)]);
         return bcast0(group_reduce<16>(part, op));
     }
     __device__ __forceinline__ float max(float v) { return all(v, OpMaxF{}, -INFINITY); }
@@ -118,7 +133,7 @@ struct BlockRed {
         unsigned long long* s = next_set();
         const int lane = threadIdx.x & 63;
         if (lane == 0) {
-            unsigned long long* rec = s + (threadIdx.x >> 6) * kSlots;
+            unsigned long long* rec = s + wave_index() * kSlots;
             rec[0] = pack(c);
             rec[1] = pack(sm);
         }
@@ -126,8 +141,9 @@ struct BlockRed {
         int pc = 0;
         float ps = 0.0f;
         if (lane < NW) {
-            pc = unpack<int>(s[lane * kSlots]);
-            ps = unpack<float>(s[lane * kSlots + 1]);
+            const int r = rec_of(lane);
+            pc = unpack<int>(s[r]);
+            ps = unpack<float>(s[r + 1]);
         }
         c = bcast0(group_reduce<16>(pc, OpSum{}));
         sm = bcast0(group_reduce<16>(ps, OpSum{}));
@@ -141,7 +157,7 @@ struct BlockRed {
         unsigned long long* s = next_set();
         const int lane = threadIdx.x & 63;
         if (lane == 0) {
-            unsigned long long* rec = s + (threadIdx.x >> 6) * kSlots;
+            unsigned long long* rec = s + wave_index() * kSlots;
             rec[0] = ((unsigned long long)(unsigned)t << 32) | (unsigned)mg;
             rec[1] = pack(S);
             rec[2] = pack(vn);
@@ -151,11 +167,12 @@ struct BlockRed {
         double pS = 0.0;
         float pv = -INFINITY;
         if (lane < NW) {
-            unsigned long long w = s[lane * kSlots];
+            const int r = rec_of(lane);
+            unsigned long long w = s[r];
             pm = (int)(unsigned)(w & 0xffffffffull);
             pt = (int)(unsigned)(w >> 32);
-            pS = unpack<double>(s[lane * kSlots + 1]);
-            pv = unpack<float>(s[lane * kSlots + 2]);
+            pS = unpack<double>(s[r + 1]);
+            pv = unpack<float>(s[r + 2]);
         }
         mg = bcast0(group_reduce<16>(pm, OpSum{}));
         t = bcast0(group_reduce<16>(pt, OpSum{}));
@@ -233,7 +250,7 @@ __device__ __forceinline__ float cand_floor(int K)
     return -1.0f;
 #endif
     const float a = 3.0f * (float)K * 0x1p-23f;
-    return -((1.0f + 0x1p-23f) / (1.0f - a)) * (1.0f + 1e-5f);
+    return uniform(-((1.0f + 0x1p-23f) / (1.0f - a)) * (1.0f + 1e-5f));
 }
 
 struct Edge {
@@ -474,7 +491,7 @@ constexpr int kLazyTry = 2 * kCandCap;      // attempt the compaction once |{z >
 constexpr float kLazyMargin = 1e-3f;
 __device__ __forceinline__ bool lazy_list_is_complete(float thr, float tau_k, int m_robust, int K)
 {
-    const float a = 3.0f * (float)K * 0x1p-23f;
+    const float a = uniform(3.0f * (float)K * 0x1p-23f);
     const float m = (float)m_robust;
     const float tl = fabsf(tau_k) + 1e-5f;   // |lower bound of tau|, fp32 slop of tau_k included
     return m > a && fabsf(thr) * (m - a) > (m * tl + 0x1p-23f) * (1.0f + 1e-5f);
@@ -482,7 +499,7 @@ __device__ __forceinline__ bool lazy_list_is_complete(float thr, float tau_k, in
 // the highest cut that passes the check above (-inf when none does: use the floor)
 __device__ __forceinline__ float lazy_complete_thr(float tau_k, int m_robust, int K)
 {
-    const float a = 3.0f * (float)K * 0x1p-23f;
+    const float a = uniform(3.0f * (float)K * 0x1p-23f);
     const float m = (float)m_robust;
     const float tl = fabsf(tau_k) + 1e-5f;
     return m > a ? -((m * tl + 0x1p-23f) * (1.0f + 1e-5f) / (m - a)) * (1.0f + 1e-5f) - 1e-6f : -INFINITY;
@@ -625,7 +642,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 wave_lds_sync();
             }
         } else {
-            const int wave = threadIdx.x >> 6;
+            const int wave = wave_index();
             int* cnt = reinterpret_cast<int*>(cand + NW * 64);
             int* ccols = list ? cnt + NW : nullptr;   // NW*64 candidate columns after the counts
             // candidates above the floor first; if they do not fit (narrow logit distribution),
@@ -872,7 +889,9 @@ __device__ __forceinline__ void load_row(const float* __restrict__ row, int K, i
             int f = i * GT + gl;
             float4 v = make_float4(pad, pad, pad, pad);
             // (uniform base of each group of 4 chunks) + (lane offset) + (immediate < 4 KB)
-            if (FULL || f < K4) v = nt_load4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl));
+            if (FULL || f < K4)
+                v = (UNI && !FULL) ? nt_load4((r4 + i * GT) + gl)   // ragged workgroup tile: scalar base per chunk
+                        : nt_load4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl));
             z[4 * i + 0] = v.x; z[4 * i + 1] = v.y; z[4 * i + 2] = v.z; z[4 * i + 3] = v.w;
         }
     } else if constexpr (UNI) {
@@ -907,7 +926,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ row, int K, int gl
         for (int i = 0; i < E / 4; ++i) {
             int f = i * GT + gl;
             if (FULL || f < K4)
-                nt_store4((r4 + (i & ~3) * GT) + ((i & 3) * GT + gl),
+                nt_store4((UNI && !FULL) ? (r4 + i * GT) + gl : (r4 + (i & ~3) * GT) + ((i & 3) * GT + gl),
                           make_float4(z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]));
         }
     } else if constexpr (UNI) {
