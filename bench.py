@@ -447,6 +447,8 @@ def train_steps_bench(dev, world, rank):
         res["cfg2_signal_game_marg_sparsemax_K256_b64"] = run(m, b, 64)
         m, b = bm.make_signal_game(dev, 64, compact=True)
         res["cfg2_signal_game_marg_sparsemax_K256_b64_compact"] = run(m, b, 64)
+        m, b = bm.make_signal_game(dev, 64, compact=True, hoist=True)
+        res["cfg2_signal_game_marg_sparsemax_K256_b64_compact_hoisted"] = run(m, b, 64)
         m, b = bm.make_bitvae(dev, 64, 32, "sparsemap")
         res["cfg4_bitvae_sparsemap_32bits_b64"] = run(m, b, 64)
         m, b = bm.make_bitvae(dev, 64, 32, "sparsemap", fused_decoder=False)

@@ -93,8 +93,11 @@ class _Receiver(nn.Module):
         self.lin1 = nn.Linear(feat, emb, bias=False)
         self.lin2 = nn.Embedding(vocab, emb)
 
-    def forward(self, signal, x):
-        embs = torch.stack([self.lin1(x[i]) for i in range(self.game_size)], dim=1)  # [B, G, emb]
+    def return_embeddings(self, x):                                 # archs.py:91-105
+        return torch.stack([self.lin1(x[i]) for i in range(self.game_size)], dim=1)  # [B, G, emb]
+
+    def forward(self, signal, x):                                   # archs.py:72-89
+        embs = self.return_embeddings(x)
         out = torch.bmm(embs, self.lin2(signal).unsqueeze(-1)).squeeze(-1)
         return F.log_softmax(out, dim=1)
 
@@ -104,13 +107,17 @@ def _game_loss(_sender_input, message, _receiver_input, receiver_output, labels)
     return nll, {'acc': (receiver_output.argmax(1) == labels).float()}
 
 
-def make_signal_game(dev, batch=64, game_size=16, feat=4096, vocab=256, seed=0, compact=False):
+def make_signal_game(dev, batch=64, game_size=16, feat=4096, vocab=256, seed=0, compact=False,
+                     hoist=False):
     torch.manual_seed(seed)
     # receiver input is [game_size, B, feat]: the batch axis is 1; the sender input is not needed
-    # by the loss, so it is not gathered (batch_dims[0] = None)
+    # by the loss, so it is not gathered (batch_dims[0] = None).  hoist: the Receiver embeds the
+    # game_size images once per batch and the (row, z) pairs gather the embeddings, so the images
+    # are not gathered either (the loss does not look at them).
     model = Marginalizer(ExplicitWrapper(_Sender(feat, 256, 512, vocab), normalizer='sparsemax'),
                          DeterministicWrapper(_Receiver(game_size, feat, 256, vocab)), _game_loss,
-                         encoder_entropy_coeff=0.1, compact=compact, batch_dims=(None, 1)).to(dev)
+                         encoder_entropy_coeff=0.1, compact=compact, hoist=bool(hoist),
+                         batch_dims=(None, None if hoist else 1)).to(dev)
     x = torch.randn(game_size, batch, feat, device=dev)       # sender input: x[0] is the target
     labels = torch.randint(0, game_size, (batch,), device=dev)
     recv = x.clone()                                            # receiver sees it at slot labels[b]

@@ -10,6 +10,14 @@ call ``.materialize()`` to get the dense tensor the reference would have produce
 
 ``support_logsumexp`` replaces the per-sample Python loop of compute_importance_sampling
 (experiments/bit_vector-vae/train.py:325-330).
+
+``hoisted_decoder`` is the compaction-aware decoder hook of ``Marginalizer(compact=True)``: the part
+of a decoder that depends on the decoder input only is computed ONCE per batch and the (row, z)
+pairs of the support gather from it.  The signal game's Receiver
+(experiments/signal-game/archs.py:72-105) is the case it exists for: its forward embeds all
+``game_size`` candidate images of every row for every message z; hoisted, the ``game_size`` images
+are embedded once per batch (``return_embeddings``), the N pairs gather their row's ``[game_size,
+emb]`` block and one ``bmm`` with the N message embeddings gives the N x game_size scores.
 """
 import torch
 import torch.nn.functional as F
@@ -71,3 +79,40 @@ def support_logsumexp(values, idxs, batch_size, shift=0.0):
     off = torch.zeros(batch_size + 1, dtype=torch.int64, device=dev)
     off[1:] = torch.cumsum(counts, 0)
     return _native.segmented_logsumexp(values.detach().to(torch.float32).contiguous(), off, shift)
+
+
+class HoistedReceiver:
+    """The two-phase view of a module shaped like the signal game's Receiver
+    (experiments/signal-game/archs.py:59-105): ``return_embeddings(x) -> [B, game_size, emb]`` and a
+    message embedding ``lin2``.  ``decode_pairs`` repeats archs.py:76-89 on gathered rows."""
+
+    def __init__(self, receiver):
+        self.receiver = receiver
+
+    def embed_once(self, decoder_input):
+        return self.receiver.return_embeddings(decoder_input)
+
+    def decode_pairs(self, z, embeddings, rows):
+        signal = z
+        if signal.dim() == 3:
+            signal = signal.squeeze(dim=-1)
+        h_s = self.receiver.lin2(signal)                              # [N, emb]
+        out = torch.bmm(embeddings.index_select(0, rows), h_s.unsqueeze(-1)).squeeze(-1)
+        return F.log_softmax(out, dim=1)
+
+
+def hoisted_decoder(decoder):
+    """The two-phase interface of ``decoder`` (a DeterministicWrapper or a bare module), or None.
+
+    A decoder takes part by defining ``embed_once(decoder_input) -> state`` (any tensor or structure
+    whose leading axis is the batch where it is a tensor) and ``decode_pairs(z [N], state, rows [N])
+    -> decoder output for the N pairs``; modules with the reference Receiver's members
+    (``return_embeddings``, ``lin2``) are adapted as they are, so the unchanged signal-game script
+    gets the hoisted path under ``LVMHELPERS_COMPACT=1``."""
+    agent = getattr(decoder, 'agent', decoder)
+    if callable(getattr(agent, 'embed_once', None)) and callable(getattr(agent, 'decode_pairs', None)):
+        return agent
+    if callable(getattr(agent, 'return_embeddings', None)) and isinstance(
+            getattr(agent, 'lin2', None), torch.nn.Module):
+        return HoistedReceiver(agent)
+    return None

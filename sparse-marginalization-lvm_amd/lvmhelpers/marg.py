@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from . import _native
 from . import functional as F_
+from . import fused
 
 
 def entropy(p: torch.Tensor):
@@ -63,10 +64,18 @@ class Marginalizer(torch.nn.Module):
     ``compact=True`` (keyword only here; or ``LVMHELPERS_COMPACT=1`` in the environment for
     unchanged scripts) is the support-only mode the compaction kernel exists for: the (row, latent)
     pairs with p > 0 are listed, the inputs are gathered by row along ``batch_dims = (encoder_input
-    dim, decoder_input dim)`` (``None`` = hand the tensor over as it is) and the decoder and the loss
+    dim, decoder_input dim)`` (``None`` = hand the tensor over as it is; default (0, 0), or
+    ``LVMHELPERS_BATCH_DIMS="none,1"`` in the environment) and the decoder and the loss
     run ONCE over N = sum_b |supp_b| rows instead of B rows for each of the |union of supports|
     live columns.  Loss, gradients and every log value are the same sums in a different order; a
     decoder that draws random numbers (the SSVAE's) consumes the generator differently.
+
+    ``hoist`` (compact mode; default: whenever the decoder offers it, see ``fused.hoisted_decoder``):
+    the decoder's input-only part runs once per batch on the UNgathered ``decoder_input`` and the
+    pairs gather from its result -- for the signal game's Receiver
+    (experiments/signal-game/archs.py:72-105) that is 16 image embeddings per row instead of 16 per
+    (row, z) pair, and the [game_size, N, feat] gather of the images disappears.  The loss is then
+    handed ``decoder_input`` gathered only if ``batch_dims[1]`` is not None.
     """
 
     def __init__(
@@ -78,7 +87,8 @@ class Marginalizer(torch.nn.Module):
             decoder_entropy_coeff=0.0,
             *,
             compact=None,
-            batch_dims=(0, 0)):
+            batch_dims=None,
+            hoist=None):
         super().__init__()
         self.encoder = encoder
         self.decoder = decoder
@@ -86,7 +96,13 @@ class Marginalizer(torch.nn.Module):
         self.encoder_entropy_coeff = encoder_entropy_coeff
         self.decoder_entropy_coeff = decoder_entropy_coeff
         self.compact = (os.environ.get("LVMHELPERS_COMPACT") == "1") if compact is None else bool(compact)
+        if batch_dims is None:   # unchanged scripts: LVMHELPERS_BATCH_DIMS="none,1" (signal game)
+            spec = os.environ.get("LVMHELPERS_BATCH_DIMS", "0,0").split(",")
+            if len(spec) != 2:
+                raise ValueError("LVMHELPERS_BATCH_DIMS: two comma-separated entries (an axis or 'none')")
+            batch_dims = tuple(None if e.strip().lower() == "none" else int(e) for e in spec)
         self.batch_dims = batch_dims
+        self.hoist = hoist
 
     def _forward_compact(self, encoder_input, decoder_input, labels, discrete_latent_z,
                          encoder_probs, encoder_entropy):
@@ -98,11 +114,23 @@ class Marginalizer(torch.nn.Module):
             raise RuntimeError("Marginalizer: the encoder distribution has no live category")
 
         def take(t, dim):
-            return t if dim is None else t.index_select(dim, rows_l)
+            if dim is None:
+                return t
+            if isinstance(t, (list, tuple)):   # a list of per-slot tensors counts as axis 0
+                return type(t)(take(e, dim - 1) for e in t)
+            return t.index_select(dim, rows_l)
 
         encoder_input_sel = take(encoder_input, self.batch_dims[0])
-        decoder_input_sel = take(decoder_input, self.batch_dims[1])
-        decoder_output = self.decoder(cols_l, decoder_input_sel)
+        two_phase = None if self.hoist is False else fused.hoisted_decoder(self.decoder)
+        if self.hoist and two_phase is None:
+            raise TypeError("Marginalizer(hoist=True): the decoder defines neither embed_once/"
+                            "decode_pairs nor return_embeddings/lin2")
+        if two_phase is not None:
+            decoder_output = two_phase.decode_pairs(cols_l, two_phase.embed_once(decoder_input), rows_l)
+            decoder_input_sel = take(decoder_input, self.batch_dims[1])
+        else:
+            decoder_input_sel = take(decoder_input, self.batch_dims[1])
+            decoder_output = self.decoder(cols_l, decoder_input_sel)
         loss_n, logs = self.loss(
             encoder_input_sel, discrete_latent_z[rows_l], decoder_input_sel, decoder_output,
             labels[rows_l])

@@ -295,3 +295,72 @@ def test_marginalizer_compact_equals_dense(dev, K, coeff):
     assert torch.equal(o0["log"]["distr"], o1["log"]["distr"])
     for a, b in zip(g0, g1):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def _signal_game_run(dev, compact, hoist, list_input=False):
+    import bench_models as bm
+    model, (x, recv, labels) = bm.make_signal_game(dev, 64, compact=compact, hoist=hoist)
+    if list_input:   # the Receiver only indexes x[i]: a list of game_size [B, feat] tensors works too
+        recv = [recv[i] for i in range(recv.shape[0])]
+    out = model(x, recv, labels)
+    out["loss"].backward()
+    return out, [p.grad.clone() for p in model.parameters()]
+
+
+def test_receiver_hoisting_equals_dense_column_loop(dev):
+    """SURVEY 8(f).2 on the config-2 shape (B=64, 16 images of 4096 features, vocabulary 256): the
+    hoisted decoder path -- images embedded once per batch, (row, z) pairs gather the embeddings, one
+    bmm (experiments/signal-game/archs.py:72-105 restructured) -- against the reference's column
+    loop (lvmhelpers/marg.py:86-126) and against the plain support-only mode: same loss, logs and
+    parameter gradients (fp32 sums in a different order: 1e-5 relative)."""
+    o0, g0 = _signal_game_run(dev, False, False)
+    o1, g1 = _signal_game_run(dev, True, False)
+    o2, g2 = _signal_game_run(dev, True, True)
+    o3, g3 = _signal_game_run(dev, True, True, list_input=True)
+    assert float(o0["log"]["support"]) > 1.0          # a real marginalisation, not one column per row
+    for o, g in ((o1, g1), (o2, g2), (o3, g3)):
+        assert sorted(o0["log"].keys()) == sorted(o["log"].keys())
+        assert abs(float(o0["loss"]) - float(o["loss"])) <= 1e-5 * max(1.0, abs(float(o0["loss"])))
+        for k in ("loss", "acc", "encoder_entropy", "support"):
+            assert abs(float(o0["log"][k]) - float(o["log"][k])) <= 1e-5 * max(1.0, abs(float(o0["log"][k])))
+        assert torch.equal(o0["log"]["distr"], o["log"]["distr"])
+        for a, b in zip(g0, g):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1e-3, float(a.abs().max()))
+
+
+def test_hoisting_hook_protocol(dev):
+    """A decoder takes part with embed_once/decode_pairs; hoist=True on a decoder without either
+    interface is an error, hoist=False keeps the gathered call."""
+    from lvmhelpers import fused
+    from lvmhelpers.marg import ExplicitWrapper, Marginalizer
+    from lvmhelpers.utils import DeterministicWrapper
+    from toy_models import CatDecoder, ScoreTable, cat_loss, _seeded
+    B, D, K = 16, 6, 12
+
+    class TwoPhase(CatDecoder):
+        calls = 0
+
+        def embed_once(self, decoder_input):
+            TwoPhase.calls += 1
+            return decoder_input * 1.0
+
+        def decode_pairs(self, z, state, rows):
+            return self.forward(z, state.index_select(0, rows))
+
+    outs = []
+    for cls, hoist in ((CatDecoder, None), (TwoPhase, None), (TwoPhase, False)):
+        enc = ScoreTable(B, K, scale=1.0)
+        with torch.no_grad():
+            enc.table.copy_(torch.randn(B, K, generator=torch.Generator().manual_seed(5)) * 1.5)
+        dec = _seeded(cls(K, D), 11)
+        x = torch.randn(B, D, generator=torch.Generator().manual_seed(6)).to(dev)
+        labels = torch.randint(0, K, (B,), generator=torch.Generator().manual_seed(7)).to(dev)
+        model = Marginalizer(ExplicitWrapper(enc.to(dev), normalizer="sparsemax"),
+                             DeterministicWrapper(dec.to(dev)), cat_loss, compact=True, hoist=hoist)
+        outs.append(float(model(x, x, labels)["loss"]))
+    assert TwoPhase.calls == 1
+    assert max(abs(outs[0] - outs[1]), abs(outs[1] - outs[2])) <= 1e-6 * max(1.0, abs(outs[0]))
+    assert fused.hoisted_decoder(DeterministicWrapper(CatDecoder(K, D))) is None
+    with pytest.raises(TypeError):
+        Marginalizer(ExplicitWrapper(enc, normalizer="sparsemax"), DeterministicWrapper(CatDecoder(K, D).to(dev)),
+                     cat_loss, compact=True, hoist=True)(x, x, labels)

@@ -13,8 +13,8 @@ def _steps(model, batch, n=6, lr=1e-3):
     return [float(bm.train_step(model, opt, batch)["loss"]) for _ in range(n)]
 
 
-@pytest.mark.parametrize("name", ["ssvae", "signal_game", "bitvae_sparsemap", "bitvae_budget",
-                                  "bitvae_topk", "bitvae_sparsemap_128"])
+@pytest.mark.parametrize("name", ["ssvae", "signal_game", "signal_game_hoisted", "bitvae_sparsemap",
+                                  "bitvae_budget", "bitvae_topk", "bitvae_sparsemap_128"])
 def test_config_trains(dev, name):
     import bench_models as bm
     torch.manual_seed(1)
@@ -22,6 +22,8 @@ def test_config_trains(dev, name):
         model, batch = bm.make_ssvae(dev, 64)
     elif name == "signal_game":
         model, batch = bm.make_signal_game(dev, 64)
+    elif name == "signal_game_hoisted":
+        model, batch = bm.make_signal_game(dev, 64, compact=True, hoist=True)
     elif name == "bitvae_sparsemap":
         model, batch = bm.make_bitvae(dev, 64, 32, "sparsemap")
     elif name == "bitvae_budget":
