@@ -66,6 +66,15 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 struct OpSum { template <class T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
 struct OpMaxF { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
 struct OpMinF { __device__ __forceinline__ float operator()(float a, float b) const { return fminf(a, b); } };
+struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wave execute in order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // All-reduce over groups of G consecutive lanes (G in {8,16,32,64}) of one wave: every lane of a
 // group ends with the group's result, bitwise identical in all of them (each step combines the

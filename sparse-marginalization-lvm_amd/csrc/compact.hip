@@ -24,6 +24,24 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
 // lists (optional): the forward's support lists (include/sparsemarg.h, smlvm_sparsemax_fwd_cols);
 // a row that has one is counted / compacted from its <= cap entries without touching its K
 // probabilities, a row marked -2 is scanned as before.
+// one wave counts the positive entries of one row
+template <bool VEC>
+__device__ __forceinline__ int count_row_scan(const float* __restrict__ pr, int K, int lane)
+{
+    int c = 0;
+    if constexpr (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const int K4 = K >> 2;
+        for (int f = lane; f < K4; f += 64) {
+            float4 v = p4[f];
+            c += (v.x > 0.0f) + (v.y > 0.0f) + (v.z > 0.0f) + (v.w > 0.0f);
+        }
+    } else {
+        for (int j = lane; j < K; j += 64) c += pr[j] > 0.0f;
+    }
+    return group_reduce<64>(c, OpSum{});
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void support_count_kernel(const float* __restrict__ p,
                                                             const int32_t* __restrict__ lists, int cap,
@@ -41,20 +59,97 @@ __global__ __launch_bounds__(256) void support_count_kernel(const float* __restr
             return;
         }
     }
-    const float* pr = p + row * K;
-    int c = 0;
-    if constexpr (VEC) {
-        const float4* p4 = reinterpret_cast<const float4*>(pr);
-        const int K4 = K >> 2;
-        for (int f = lane; f < K4; f += 64) {
-            float4 v = p4[f];
-            c += (v.x > 0.0f) + (v.y > 0.0f) + (v.z > 0.0f) + (v.w > 0.0f);
-        }
-    } else {
-        for (int j = lane; j < K; j += 64) c += pr[j] > 0.0f;
-    }
-    c = group_reduce<64>(c, OpSum{});
+    const int c = count_row_scan<VEC>(p + row * K, K, lane);
     if (lane == 0) nnz[row] = c;
+}
+
+// Rows of at most 256 entries (one 16-byte load per lane covers a row): a wave takes four
+// consecutive rows and issues their loads together -- with one row per wave the launch holds too
+// few bytes in flight to cover the HBM latency (4.3 TB/s at K = 256).
+__global__ __launch_bounds__(256) void support_count_short_kernel(const float* __restrict__ p,
+                                                                  int32_t* __restrict__ nnz,
+                                                                  int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= R) return;
+    const int K4 = K >> 2;
+    float4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < K4 && row0 + r < R) v[r] = reinterpret_cast<const float4*>(p + (row0 + r) * K)[lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int c = (v[r].x > 0.0f) + (v[r].y > 0.0f) + (v[r].z > 0.0f) + (v[r].w > 0.0f);
+        c = group_reduce<64>(c, OpSum{});
+        if (lane == 0 && row0 + r < R) nnz[row0 + r] = c;
+    }
+}
+
+// sum over groups of G consecutive lanes, G in {4, 8, 16}
+template <int G>
+__device__ __forceinline__ int lanes_sum(int v)
+{
+    v += dpp_i32<DPP_QUAD_XOR1>(v);
+    v += dpp_i32<DPP_QUAD_XOR2>(v);
+    if constexpr (G >= 8) v += dpp_i32<DPP_ROW_HALF_MIRROR>(v);
+    if constexpr (G >= 16) v += dpp_i32<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+// List-fed count, cap = 4 G: a group of G lanes reads one row's list as 16-byte quarters, so a
+// wave takes 64 / G rows with one load (a wave per 128-byte list made the launch latency bound: 1M
+// waves for 134 MB).  Rows without a list (first entry -2 / -3) are scanned afterwards, one at a
+// time by the whole wave.
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void support_count_lists_kernel(const float* __restrict__ p,
+                                                                  const int32_t* __restrict__ lists,
+                                                                  int32_t* __restrict__ nnz,
+                                                                  int64_t R, int K)
+{
+    constexpr int RW = 64 / G;
+    const int lane = threadIdx.x & 63, gl = lane % G;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+    if (row0 >= R) return;
+    const int64_t row = row0 + lane / G;
+    int4 q = make_int4(-1, -1, -1, -1);
+    if (row < R) q = reinterpret_cast<const int4*>(lists + row * (4 * G))[gl];
+    const int n = lanes_sum<G>((q.x >= 0) + (q.y >= 0) + (q.z >= 0) + (q.w >= 0));
+    const bool unlisted = gl == 0 && row < R && q.x < -1;
+    if (gl == 0 && row < R && !unlisted) nnz[row] = n;
+    unsigned long long todo = __ballot(unlisted);   // wave-uniform from here on
+    if (VEC && K <= 256) {   // short rows: four at a time, loads issued together
+        const int K4 = K >> 2;
+        while (todo != 0ull) {
+            int64_t rr[4];
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rr[j] = -1;
+                if (todo != 0ull) { rr[j] = row0 + __builtin_ctzll(todo) / G; todo &= todo - 1ull; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rr[j] >= 0 && lane < K4) v[j] = reinterpret_cast<const float4*>(p + rr[j] * K)[lane];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (rr[j] < 0) break;
+                int c = (v[j].x > 0.0f) + (v[j].y > 0.0f) + (v[j].z > 0.0f) + (v[j].w > 0.0f);
+                c = group_reduce<64>(c, OpSum{});
+                if (lane == 0) nnz[rr[j]] = c;
+            }
+        }
+        return;
+    }
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const int64_t r = row0 + (__builtin_ctzll(todo)) / G;
+        const int c = count_row_scan<VEC>(p + r * K, K, lane);
+        if (lane == 0) nnz[r] = c;
+    }
 }
 
 // ------------------------------------------------------------------------------- offsets
@@ -143,6 +238,69 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(const int32_t* __restri
 }
 
 // ------------------------------------------------------------------------------- compact
+// one 64-lane step of the VEC scan: `v` is this lane's float4 with index f of the row; the
+// positives go out in (lane, component) order from position `out` on (advanced by their number)
+__device__ __forceinline__ void compact_step4(float4 v, int f, int64_t row, int64_t& out,
+                                              int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                              float* __restrict__ vals)
+{
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    // positives before this lane's first one: four ballots + mbcnt instead of a shuffle scan
+    unsigned long long m[4];
+    int pre = 0, total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m[c] = __ballot(e[c] > 0.0f);
+        pre += lanes_below(m[c]);
+        total += __popcll(m[c]);
+    }
+    if (total == 0) return;  // wave-uniform: nothing in these 1 KiB
+    int64_t pos = out + pre;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (e[c] > 0.0f) {
+            if (rows) rows[pos] = (int32_t)row;
+            if (cols) cols[pos] = f * 4 + c;
+            if (vals) vals[pos] = e[c];
+            ++pos;
+        }
+    }
+    out += total;
+}
+
+// one wave compacts one row, entries in column order from position `out` on
+template <bool VEC>
+__device__ __forceinline__ void compact_row_scan(const float* __restrict__ pr, int K, int lane,
+                                                 int64_t row, int64_t out,
+                                                 int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                                 float* __restrict__ vals)
+{
+    if constexpr (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const int K4 = K >> 2;
+        for (int f0 = 0; f0 < K4; f0 += 64) {
+            const int f = f0 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < K4) v = p4[f];
+            compact_step4(v, f, row, out, rows, cols, vals);
+        }
+    } else {
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = j < K ? pr[j] : 0.0f;
+            const unsigned long long m = __ballot(v > 0.0f);
+            if (m == 0ull) continue;
+            if (v > 0.0f) {
+                const int64_t pos = out + lanes_below(m);
+                if (rows) rows[pos] = (int32_t)row;
+                if (cols) cols[pos] = j;
+                if (vals) vals[pos] = v;
+            }
+            out += __popcll(m);
+        }
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void support_compact_kernel(
     const float* __restrict__ p, const int32_t* __restrict__ lists, int cap,
@@ -153,7 +311,7 @@ __global__ __launch_bounds__(256) void support_compact_kernel(
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const float* pr = p + row * K;
-    int64_t out = row_offsets[row];
+    const int64_t out = row_offsets[row];
     if (lists) {
         const int cl = lane < cap ? lists[row * cap + lane] : -1;
         if (__builtin_amdgcn_readfirstlane(cl) >= -1) {   // wave-uniform; -2 / -3: no list
@@ -170,51 +328,113 @@ __global__ __launch_bounds__(256) void support_compact_kernel(
             return;
         }
     }
-    if constexpr (VEC) {
-        const float4* p4 = reinterpret_cast<const float4*>(pr);
-        const int K4 = K >> 2;
-        for (int f0 = 0; f0 < K4; f0 += 64) {
-            const int f = f0 + lane;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < K4) v = p4[f];
-            const float e[4] = {v.x, v.y, v.z, v.w};
-            // positives before this lane's first one, in (lane, component) order: four ballots +
-            // mbcnt instead of a shuffle scan
-            unsigned long long m[4];
-            int pre = 0, total = 0;
+    compact_row_scan<VEC>(pr, K, lane, row, out, rows, cols, vals);
+}
+
+// Rows of at most 256 entries: four consecutive rows per wave, their loads issued together (see
+// support_count_short_kernel).
+__global__ __launch_bounds__(256) void support_compact_short_kernel(
+    const float* __restrict__ p, const int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows,
+    int32_t* __restrict__ cols, float* __restrict__ vals, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= R) return;
+    const int K4 = K >> 2;
+    float4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                m[c] = __ballot(e[c] > 0.0f);
-                pre += lanes_below(m[c]);
-                total += __popcll(m[c]);
+    for (int r = 0; r < 4; ++r) {
+        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < K4 && row0 + r < R) v[r] = reinterpret_cast<const float4*>(p + (row0 + r) * K)[lane];
+    }
+    // rows are consecutive, so are their output ranges: one offset load, then running positions
+    int64_t out = row_offsets[row0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) compact_step4(v[r], lane, row0 + r, out, rows, cols, vals);
+}
+
+// List-fed compaction, cap = 4 G (see support_count_lists_kernel): 64 / G rows per wave.  The
+// lists are in no particular order, so an entry's output slot is the rank of its column inside its
+// row: the wave parks its lists in LDS and every lane compares its four entries with the first
+// n_max entries of its row (n_max = longest list in the wave; entries are packed at the front).
+template <int G, bool VEC>
+__global__ __launch_bounds__(256) void support_compact_lists_kernel(
+    const float* __restrict__ p, const int32_t* __restrict__ lists,
+    const int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows,
+    int32_t* __restrict__ cols, float* __restrict__ vals, int64_t R, int K)
+{
+    constexpr int RW = 64 / G, CAP = 4 * G;
+    __shared__ int parked[4][64 * 4];
+    const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * RW;
+    if (row0 >= R) return;
+    const int64_t row = row0 + grp;
+    int4 q = make_int4(-1, -1, -1, -1);
+    int64_t out = 0;
+    if (row < R) {
+        q = reinterpret_cast<const int4*>(lists + row * CAP)[gl];
+        out = row_offsets[row];
+    }
+    const bool unlisted = __shfl(q.x, grp * G) < -1;    // the row's first entry, in all its lanes
+    const int c[4] = {q.x, q.y, q.z, q.w};
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n += (!unlisted && c[i] >= 0) ? 1 : 0;
+    n = lanes_sum<G>(n);
+    int n_max = n;
+    n_max = group_reduce<64>(n_max, OpMaxI{});
+    int* mine = parked[wave] + grp * CAP;
+    reinterpret_cast<int4*>(mine)[gl] = q;
+    wave_lds_sync();
+    int rank[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_max; ++k) {   // wave-uniform trip count
+        // unsigned compare: the -1 padding of a shorter list is larger than every column
+        const unsigned other = (unsigned)mine[k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rank[i] += other < (unsigned)c[i] ? 1 : 0;
+    }
+    if (!unlisted) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (c[i] >= 0) {
+                const int64_t pos = out + rank[i];
+                if (rows) rows[pos] = (int32_t)row;
+                if (cols) cols[pos] = c[i];
+                if (vals) vals[pos] = p[row * K + c[i]];
             }
-            if (total == 0) continue;  // wave-uniform: nothing in these 1 KiB
-            int64_t pos = out + pre;
+        }
+    }
+    unsigned long long todo = __ballot(unlisted && gl == 0 && row < R);   // wave-uniform from here on
+    if (VEC && K <= 256) {   // short rows: four at a time, loads issued together
+        const int K4 = K >> 2;
+        while (todo != 0ull) {
+            int64_t rr[4], o[4];
+            float4 v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (e[c] > 0.0f) {
-                    if (rows) rows[pos] = (int32_t)row;
-                    if (cols) cols[pos] = f * 4 + c;
-                    if (vals) vals[pos] = e[c];
-                    ++pos;
+            for (int j = 0; j < 4; ++j) {
+                rr[j] = -1;
+                if (todo != 0ull) { rr[j] = row0 + __builtin_ctzll(todo) / G; todo &= todo - 1ull; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                o[j] = 0;
+                if (rr[j] >= 0) {
+                    o[j] = row_offsets[rr[j]];
+                    if (lane < K4) v[j] = reinterpret_cast<const float4*>(p + rr[j] * K)[lane];
                 }
             }
-            out += total;
-        }
-    } else {
-        for (int j0 = 0; j0 < K; j0 += 64) {
-            const int j = j0 + lane;
-            const float v = j < K ? pr[j] : 0.0f;
-            const unsigned long long m = __ballot(v > 0.0f);
-            if (m == 0ull) continue;
-            if (v > 0.0f) {
-                const int64_t pos = out + lanes_below(m);
-                if (rows) rows[pos] = (int32_t)row;
-                if (cols) cols[pos] = j;
-                if (vals) vals[pos] = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (rr[j] < 0) break;
+                compact_step4(v[j], lane, rr[j], o[j], rows, cols, vals);
             }
-            out += __popcll(m);
         }
+        return;
+    }
+    for (; todo != 0ull; todo &= todo - 1ull) {
+        const int64_t r = row0 + __builtin_ctzll(todo) / G;
+        compact_row_scan<VEC>(p + r * K, K, lane, r, row_offsets[r], rows, cols, vals);
     }
 }
 
@@ -304,10 +524,23 @@ static int support_count_go(const float* p, const int32_t* lists, int32_t cap, i
     if (R == 0) return SMLVM_OK;
     if (!p || !nnz) return SMLVM_ERR_INVALID;
     const unsigned grid = (unsigned)((R + 3) / 4);
-    if (K % 4 == 0 && aligned16(p))
-        hipLaunchKernelGGL(support_count_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, nnz, R, K);
+    const bool vec = K % 4 == 0 && aligned16(p);
+    hipStream_t st = (hipStream_t)stream;
+    auto grid_for = [&](int rows_per_wave) { return dim3((unsigned)((R + 4 * rows_per_wave - 1) / (4 * rows_per_wave))); };
+    if (lists && aligned16(lists) && (cap == 16 || cap == 32 || cap == 64)) {
+#define SMLVM_COUNT_LISTS(G)                                                                                     \
+    if (vec) hipLaunchKernelGGL((support_count_lists_kernel<G, true>), grid_for(64 / G), dim3(256), 0, st, p, lists, nnz, R, K); \
+    else hipLaunchKernelGGL((support_count_lists_kernel<G, false>), grid_for(64 / G), dim3(256), 0, st, p, lists, nnz, R, K)
+        if (cap == 16) { SMLVM_COUNT_LISTS(4); }
+        else if (cap == 32) { SMLVM_COUNT_LISTS(8); }
+        else { SMLVM_COUNT_LISTS(16); }
+#undef SMLVM_COUNT_LISTS
+    } else if (!lists && vec && K <= 256)
+        hipLaunchKernelGGL(support_count_short_kernel, grid_for(4), dim3(256), 0, st, p, nnz, R, K);
+    else if (vec)
+        hipLaunchKernelGGL(support_count_kernel<true>, dim3(grid), dim3(256), 0, st, p, lists, cap, nnz, R, K);
     else
-        hipLaunchKernelGGL(support_count_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, nnz, R, K);
+        hipLaunchKernelGGL(support_count_kernel<false>, dim3(grid), dim3(256), 0, st, p, lists, cap, nnz, R, K);
     return check_launch();
 }
 
@@ -409,10 +642,23 @@ static int support_compact_go(const float* p, const int32_t* lists, int32_t cap,
     if (R == 0) return SMLVM_OK;
     if (!p || !row_offsets) return SMLVM_ERR_INVALID;
     const unsigned grid = (unsigned)((R + 3) / 4);
-    if (K % 4 == 0 && aligned16(p))
-        hipLaunchKernelGGL(support_compact_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, row_offsets, rows, cols, vals, R, K);
+    const bool vec = K % 4 == 0 && aligned16(p);
+    hipStream_t st = (hipStream_t)stream;
+    auto grid_for = [&](int rows_per_wave) { return dim3((unsigned)((R + 4 * rows_per_wave - 1) / (4 * rows_per_wave))); };
+    if (lists && aligned16(lists) && (cap == 16 || cap == 32 || cap == 64)) {
+#define SMLVM_COMPACT_LISTS(G)                                                                                   \
+    if (vec) hipLaunchKernelGGL((support_compact_lists_kernel<G, true>), grid_for(64 / G), dim3(256), 0, st, p, lists, row_offsets, rows, cols, vals, R, K); \
+    else hipLaunchKernelGGL((support_compact_lists_kernel<G, false>), grid_for(64 / G), dim3(256), 0, st, p, lists, row_offsets, rows, cols, vals, R, K)
+        if (cap == 16) { SMLVM_COMPACT_LISTS(4); }
+        else if (cap == 32) { SMLVM_COMPACT_LISTS(8); }
+        else { SMLVM_COMPACT_LISTS(16); }
+#undef SMLVM_COMPACT_LISTS
+    } else if (!lists && vec && K <= 256)
+        hipLaunchKernelGGL(support_compact_short_kernel, grid_for(4), dim3(256), 0, st, p, row_offsets, rows, cols, vals, R, K);
+    else if (vec)
+        hipLaunchKernelGGL(support_compact_kernel<true>, dim3(grid), dim3(256), 0, st, p, lists, cap, row_offsets, rows, cols, vals, R, K);
     else
-        hipLaunchKernelGGL(support_compact_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, lists, cap, row_offsets, rows, cols, vals, R, K);
+        hipLaunchKernelGGL(support_compact_kernel<false>, dim3(grid), dim3(256), 0, st, p, lists, cap, row_offsets, rows, cols, vals, R, K);
     return check_launch();
 }
 

@@ -556,13 +556,6 @@ __device__ __forceinline__ int emit_cols_from_candidates(const float (&c)[Q], co
     return base;   // #{p > 0} of the row (the mark and the support mask are decided on this count)
 }
 
-__device__ __forceinline__ void wave_lds_sync()
-{
-    // LDS operations of one wave execute in order; this only pins the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
 // NW = waves holding the row (1: a lane group of one wave; then G < 64 skips the candidate path).

@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("R,K,density", [(64, 10, 0.3), (64, 256, 0.02), (1, 1, 1.0), (5, 3, 0.0),
                                          (100, 129, 0.5), (7, 4096, 0.001), (3, 65536, 0.3),
-                                         (5000, 40, 0.1), (9, 1027, 1.0)])
+                                         (5000, 40, 0.1), (9, 1027, 1.0), (1001, 256, 0.05), (13, 252, 0.5),
+                                         (4, 4, 1.0), (1 << 16, 256, 0.02)])
 def test_compact_matches_oracle(dev, oracle_mod, R, K, density):
     from lvmhelpers import _native
     rng = np.random.default_rng(R * 131 + K)
@@ -130,6 +131,38 @@ def test_compact_from_support_lists(dev, R, K, sigma):
     # compaction from lists whose overflow rows carry the mask mark
     off2, rows2, cols2, vals2 = _native.support_compact(p, support_cols=tagged)
     assert torch.equal(off2, off0) and torch.equal(cols2, cols0) and torch.equal(vals2, vals0)
+
+
+@pytest.mark.parametrize("R,K,cap", [(1, 8, 16), (7, 12, 16), (33, 256, 32), (1000, 256, 32), (65, 1000, 64),
+                                     (129, 250, 32), (50, 4096, 64), (9, 100, 8), (40, 64, 48), (257, 37, 32)])
+def test_list_fed_kernels_on_handmade_lists(dev, oracle_mod, R, K, cap):
+    """The list-fed count/compaction on lists built by hand: entries in random order, packed at the
+    front and padded with -1; every third row unlisted (-2 or -3 in slot 0, garbage behind it),
+    rows with an empty support, rows that fill the list; R ragged against the rows a wave / a
+    workgroup takes, caps on and off the multi-row path (16/32/64 vs 8/48), K on and off the 16-byte
+    path.  Expected: the oracle's compaction of p (row-major torch.nonzero order)."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(R * 7 + K * 3 + cap)
+    p = np.zeros((R, K), np.float32)
+    lists = np.full((R, cap), -1, np.int32)
+    for r in range(R):
+        kind = r % 6
+        n = int(rng.integers(0, min(cap, K) + 1)) if kind not in (1, 4) else (min(cap, K) if kind == 1 else 0)
+        cols = rng.choice(K, n, replace=False)
+        if r % 3 == 2:     # no list: any support size
+            cols = rng.choice(K, int(rng.integers(1, K + 1)), replace=False)
+            lists[r] = rng.integers(-5, K, cap)
+            lists[r, 0] = -2 if r % 2 else -3
+        else:
+            lists[r, :n] = cols
+        p[r, cols] = rng.random(len(cols)).astype(np.float32) + 0.01
+    off_ref, rows_ref, cols_ref, vals_ref = oracle_mod.support_compact(p)
+    pt, lt = torch.from_numpy(p).to(dev), torch.from_numpy(lists).to(dev)
+    off, rows, cols, vals = _native.support_compact(pt, support_cols=lt)
+    assert np.array_equal(off.cpu().numpy(), off_ref)
+    assert np.array_equal(rows.cpu().numpy(), rows_ref)
+    assert np.array_equal(cols.cpu().numpy(), cols_ref)
+    assert np.array_equal(vals.cpu().numpy(), vals_ref)
 
 
 def test_support_tag_goes_stale_when_p_is_modified(dev):
