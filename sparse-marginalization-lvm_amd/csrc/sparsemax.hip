@@ -57,6 +57,14 @@ struct WaveRed {
         S = group_reduce<G>(S, OpSum{});
         vn = group_reduce<G>(vn, OpMaxF{});
     }
+    // count, sum, smallest of a set and the largest element outside it
+    __device__ __forceinline__ void first(int& m, double& S, float& lo, float& vn)
+    {
+        m = group_reduce<G>(m, OpSum{});
+        S = group_reduce<G>(S, OpSum{});
+        lo = group_reduce<G>(lo, OpMinF{});
+        vn = group_reduce<G>(vn, OpMaxF{});
+    }
 };
 
 // Whole-workgroup all-reduce through LDS, one barrier per call: each wave reduces with DPP, lane 0
@@ -177,6 +185,37 @@ struct BlockRed {
         mg = bcast0(group_reduce<16>(pm, OpSum{}));
         t = bcast0(group_reduce<16>(pt, OpSum{}));
         S = bcast0(group_reduce<16>(pS, OpSum{}));
+        vn = bcast0(group_reduce<16>(pv, OpMaxF{}));
+    }
+    __device__ __forceinline__ void first(int& m, double& S, float& lo, float& vn)
+    {
+        m = group_reduce<64>(m, OpSum{});
+        S = group_reduce<64>(S, OpSum{});
+        lo = group_reduce<64>(lo, OpMinF{});
+        vn = group_reduce<64>(vn, OpMaxF{});
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) {
+            unsigned long long* rec = s + wave_index() * kSlots;
+            rec[0] = ((unsigned long long)__builtin_bit_cast(unsigned, lo) << 32) | (unsigned)m;
+            rec[1] = pack(S);
+            rec[2] = pack(vn);
+        }
+        __syncthreads();
+        int pm = 0;
+        double pS = 0.0;
+        float pl = INFINITY, pv = -INFINITY;
+        if (lane < NW) {
+            const int r = rec_of(lane);
+            unsigned long long w = s[r];
+            pm = (int)(unsigned)(w & 0xffffffffull);
+            pl = __builtin_bit_cast(float, (unsigned)(w >> 32));
+            pS = unpack<double>(s[r + 1]);
+            pv = unpack<float>(s[r + 2]);
+        }
+        m = bcast0(group_reduce<16>(pm, OpSum{}));
+        S = bcast0(group_reduce<16>(pS, OpSum{}));
+        lo = bcast0(group_reduce<16>(pl, OpMinF{}));
         vn = bcast0(group_reduce<16>(pv, OpMaxF{}));
     }
 };
@@ -307,27 +346,45 @@ template <class Src, class Red>
 __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, int nvis, int& s_out,
                                            double& S_out, int* m_robust = nullptr)
 {
-    float lo = INFINITY;
-    src.each([&](float v) { lo = (v > tau) ? fminf(lo, v) : lo; });
-    lo = red.min(lo);
-
-    // up to the first group that passes robustly (the top group always does: f = 1)
-    Edge b;
-    for (;;) {
-        b = edge_pass(src, lo, red);
-        if (__builtin_expect(b.m_gt == 0 || classify_group(b.m_gt, b.S_gt, lo, b.t) > 0, 1)) break;
-        float up = INFINITY;
-        src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
-        lo = red.min(up);
+    // One pass at tau: the set {v > tau} (count m_all, fp64 sum S_all), its smallest value lo and
+    // the largest value outside it.  For the tie group at lo, f = 1 + m_gt lo - S_gt is the same
+    // number as 1 + m_all lo - S_all (the group's own t lo cancels), so the usual case -- that
+    // group passes robustly -- is decided without counting the group.
+    int m_top = 0;
+    double S_top = 0.0;
+    float lo = INFINITY, vnext = -INFINITY;
+    src.each([&](float v) {
+        const bool gt = v > tau;
+        m_top += gt ? 1 : 0;
+        S_top += gt ? (double)v : 0.0;
+        lo = gt ? fminf(lo, v) : lo;
+        vnext = gt ? vnext : fmaxf(vnext, v);
+    });
+    red.first(m_top, S_top, lo, vnext);
+    bool top_ok = false;
+    if (m_top > 0) {
+        const double d = (double)m_top * (double)lo - S_top + 1.0;
+        top_ok = d > 0x1p-23 * (3.0 * (double)m_top * fabs((double)lo) + 1.0);   // classify_group's bound
     }
-    const int m_top = b.m_gt + b.t;
-    const double S_top = b.S_gt + (double)b.t * (double)lo;
+    if (__builtin_expect(!top_ok, 0)) {
+        // up to the first group that passes robustly (the top group always does: f = 1)
+        Edge b;
+        for (;;) {
+            b = edge_pass(src, lo, red);
+            if (b.m_gt == 0 || classify_group(b.m_gt, b.S_gt, lo, b.t) > 0) break;
+            float up = INFINITY;
+            src.each([&](float v) { up = (v > lo) ? fminf(up, v) : up; });
+            lo = red.min(up);
+        }
+        m_top = b.m_gt + b.t;
+        S_top = b.S_gt + (double)b.t * (double)lo;
+        vnext = b.vnext;
+    }
     if (m_robust) *m_robust = m_top;   // these ranks are in the support in exact arithmetic too
 
     // down through the groups the noise bound cannot decide
     int m = m_top, C = 0;
     double S = S_top, S_at = S_top;
-    float vnext = b.vnext;
     const float first_lo = vnext;
     bool open = true, dirty = false;   // open: the passing ranks so far are a prefix of the ranks
     while (vnext > -INFINITY) {
@@ -372,10 +429,12 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
 // must be present): Michelot iteration, then the exact edge.
 template <int E, class Red>
 __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int nvis, int& s_out,
-                                           double& S_out, int* m_robust = nullptr)
+                                           double& S_out, int* m_robust = nullptr, float tau0 = -1.0f)
 {
-    // --- Michelot iteration from the lower bound tau >= -1 (z_max = 0 after the shift).
-    float tau = -1.0f;
+    // --- Michelot iteration from a lower bound of the threshold (tau >= -1: z_max = 0 after the
+    // shift; callers may know a better one).  A start that fp32 rounding put a hair above the true
+    // threshold is as good: the edge search below walks down from where the iteration stops.
+    float tau = tau0;
     int cnt_prev = 0x7fffffff;
     for (;;) {
         int c = 0;
@@ -447,6 +506,28 @@ __device__ __forceinline__ void group_count(unsigned long long m, int gl, int gr
     }
 }
 
+
+// inclusive prefix sum over the G consecutive lanes of a group (gl = lane % G)
+template <int G>
+__device__ __forceinline__ int group_scan_incl(int v, int gl)
+{
+    static_assert(G == 8 || G == 16 || G == 32, "lane groups inside one wave");
+#define SMLVM_SCAN_STEP(D)                                                                       \
+    if constexpr (G > D) {                                                                       \
+        const int o = __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xF, 0xF, true); /* row_shr:D */ \
+        v += (G == 16 || gl >= D) ? o : 0;   /* 16-lane rows: the shift itself fills with zero */  \
+    }
+    SMLVM_SCAN_STEP(1)
+    SMLVM_SCAN_STEP(2)
+    SMLVM_SCAN_STEP(4)
+    SMLVM_SCAN_STEP(8)
+#undef SMLVM_SCAN_STEP
+    if constexpr (G == 32) {   // second 16-lane row: add the first row's total (its lane 15)
+        const int o = __shfl(v, ((int)(threadIdx.x & 63) & ~31) | 15);
+        v += gl >= 16 ? o : 0;
+    }
+    return v;
+}
 
 // Appends this wave's elements > thr to list[0..cap) in lane order per register; returns how many
 // there are (may exceed cap: then the list is incomplete and the caller must not use it).
@@ -763,40 +844,45 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     float mx = z[0];
 #pragma unroll
     for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    float lane_mx = mx;
     mx = red.max(mx);
+    lane_mx -= mx;   // this lane's largest element in the shifted frame (-inf for padding lanes)
 #pragma unroll
     for (int e = 0; e < E; ++e) z[e] -= mx;
 
     const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G;
-    const unsigned group_bits = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
-    const unsigned below_bits = (1u << gl) - 1u;
     float* clist = cand + grp * CAP;
     int* ccols = reinterpret_cast<int*>(cand + kCandCap) + grp * CAP;
-    int base = 0;
+    // candidates per lane, then each lane's first slot by a scan over the group's lanes: the
+    // per-element cost is a compare and an add (a wave-wide ballot per element with the group's
+    // bits picked out of it cost three times as much, and these rows are instruction bound)
+    int mine = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool in = z[e] > floor_k;
-        const unsigned long long m = __ballot(in);
-        if (m != 0ull) {  // wave-uniform
-            const unsigned mine = (unsigned)(m >> (grp * G)) & group_bits;
-            const int off = base + __popc(mine & below_bits);
-            if (in && off < CAP) {
-                clist[off] = z[e];
-                if (list) ccols[off] = col_of<E, VEC>(e, gl, G);
-            }
-            base += __popc(mine);
-        }
-    }
+    for (int e = 0; e < E; ++e) mine += z[e] > floor_k ? 1 : 0;
+    const int incl = group_scan_incl<G>(mine, gl);
     int s_final = 1;
     double S_final = 0.0;
     bool listed = false;
-    if (__ballot(base > CAP) == 0ull) {
+    if (__ballot(incl > CAP) == 0ull) {   // incl of a group's last lane is its total
+        const int total = __shfl(incl, lane | (G - 1));
+        int off = incl - mine;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool in = z[e] > floor_k;
+            if (__ballot(in) != 0ull) {  // wave-uniform
+                if (in) {
+                    clist[off] = z[e];
+                    if (list) ccols[off] = col_of<E, VEC>(e, gl, G);
+                }
+                off += in ? 1 : 0;
+            }
+        }
         float c[Q];
         int cc[Q];
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const bool have = gl + G * q < base;
+            const bool have = gl + G * q < total;
             c[q] = have ? clist[gl + G * q] : -INFINITY;
             cc[q] = (have && list) ? ccols[gl + G * q] : 0;
         }
@@ -808,7 +894,14 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             listed = true;
         }
     } else {
-        solve_core(z, red, K, s_final, S_final);
+        // full-width search (narrow logit distributions): start Michelot from the threshold bound
+        // of the subset made of one element per lane, its maximum -- (sum - 1) / count of them is
+        // below that subset's threshold, which is below the row's -- instead of from max - 1: for
+        // logits ~ N(0, 0.05^2) at K = 256 that is three full-width passes fewer
+        int cn = lane_mx > -INFINITY ? 1 : 0;
+        float sm = lane_mx > -INFINITY ? lane_mx : 0.0f;
+        red.cs(cn, sm);
+        solve_core(z, red, K, s_final, S_final, nullptr, fmaxf(-1.0f, (sm - 1.0f) / (float)cn));
     }
     const float c_s = (float)S_final - 1.0f;
     const float tau_f = c_s / (float)s_final;
@@ -1007,25 +1100,51 @@ __device__ __forceinline__ int emit_support_cols(const float (&p)[E], int gl, in
                                                   int32_t* __restrict__ list, int cap, bool live,
                                                   int mark = kColsOverflow)
 {
-    int base = 0;
-    bool wrote0 = false;
+    if constexpr (G < 64) {
+        // several rows per wave: count per lane, scan over the group's lanes, and only rows whose
+        // support fits write columns (each lane its own, from its first slot on) -- a row that
+        // overflows costs the count and the mark (these tiles are instruction bound)
+        int mine = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool nz = p[e] > 0.0f;
-        const unsigned long long m = __ballot(nz);
-        if (m != 0ull) {
-            int cnt, below;
-            group_count<G>(m, gl, grp, cnt, below);
-            const int off = base + below;
-            if (nz && live && off < cap) { list[off] = col_of<E, VEC>(e, gl, G); wrote0 = wrote0 || off == 0; }
-            base += cnt;
+        for (int e = 0; e < E; ++e) mine += p[e] > 0.0f ? 1 : 0;
+        const int incl = group_scan_incl<G>(mine, gl);
+        const int total = __shfl(incl, (int)(threadIdx.x & 63) | (G - 1));
+        const bool fits = total <= cap;
+        if (__ballot(fits && live) != 0ull) {
+            int off = incl - mine;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool nz = p[e] > 0.0f;
+                if (nz && fits && live) list[off] = col_of<E, VEC>(e, gl, G);
+                off += nz ? 1 : 0;
+            }
         }
+        if (live) {
+            if (fits) for (int j = total + gl; j < cap; j += G) list[j] = kColsNone;
+            else for (int j = gl; j < cap; j += G) list[j] = j == 0 ? mark : kColsNone;
+        }
+        return total;
+    } else {
+        int base = 0;
+        bool wrote0 = false;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool nz = p[e] > 0.0f;
+            const unsigned long long m = __ballot(nz);
+            if (m != 0ull) {
+                int cnt, below;
+                group_count<G>(m, gl, grp, cnt, below);
+                const int off = base + below;
+                if (nz && live && off < cap) { list[off] = col_of<E, VEC>(e, gl, G); wrote0 = wrote0 || off == 0; }
+                base += cnt;
+            }
+        }
+        if (live) {
+            if (base > cap) { if (wrote0) list[0] = mark; }
+            else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
+        }
+        return base;
     }
-    if (live) {
-        if (base > cap) { if (wrote0) list[0] = mark; }
-        else for (int j = base + gl; j < cap; j += G) list[j] = kColsNone;
-    }
-    return base;
 }
 
 // dx of a row from its support list, in two rounds of stores: the whole row as zeros (no

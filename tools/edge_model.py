@@ -71,17 +71,25 @@ def solve(zv, nvis, stats):
         cp = c
         s = F(z[inn].sum(dtype=F))
         tau = max(tau, F((s - F(1.0)) / F(c)))
-    lo = F(z[z > tau].min())
-    while True:
-        b = edge(z, lo)
-        stats["edge"] += 1
-        if classify(b["m"], b["S"], lo, b["t"]) > 0:
-            break
-        lo = F(z[z > lo].min())
-        stats["up"] += 1
-    m_top = b["m"] + b["t"]
-    S_top = b["S"] + float(b["t"]) * float(lo)
-    m, S, vnext = m_top, S_top, b["vnext"]
+    # first pass at tau: the set {z > tau}, its smallest value and the largest value outside it; the
+    # tie group at lo has f = 1 + m_all lo - S_all (its own t lo cancels)
+    inn = z > tau
+    lo = F(z[inn].min())
+    m_top, S_top = int(inn.sum()), float(z[inn].astype(np.float64).sum())
+    vnext = float(z[~inn].max()) if (~inn).any() else -np.inf
+    stats["edge"] += 1
+    if not (float(m_top) * float(lo) - S_top + 1.0 > EPS23 * (3.0 * m_top * abs(float(lo)) + 1.0)):
+        while True:
+            b = edge(z, lo)
+            stats["edge"] += 1
+            if b["m"] == 0 or classify(b["m"], b["S"], lo, b["t"]) > 0:
+                break
+            lo = F(z[z > lo].min())
+            stats["up"] += 1
+        m_top = b["m"] + b["t"]
+        S_top = b["S"] + float(b["t"]) * float(lo)
+        vnext = b["vnext"]
+    m, S = m_top, S_top
     first_lo = vnext
     C, opened, dirty, S_at = 0, True, False, S_top
     while vnext > -np.inf:
