@@ -839,8 +839,9 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
 {
     const float floor_k = cand_floor(K);
     static_assert(G < 64, "lane groups inside one wave");
-    constexpr int Q = (G >= 16) ? 2 : 32 / G;   // candidates per lane: capacity G*Q = 32, 32, 64
+    constexpr int Q = 4;          // candidates per lane: capacity 4 G = 32, 64, 128 per row
     constexpr int CAP = G * Q;
+    static_assert((64 / G) * CAP <= kCandCap, "the wave's LDS slice holds every group's list");
     float mx = z[0];
 #pragma unroll
     for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
@@ -853,22 +854,24 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G;
     float* clist = cand + grp * CAP;
     int* ccols = reinterpret_cast<int*>(cand + kCandCap) + grp * CAP;
-    // candidates per lane, then each lane's first slot by a scan over the group's lanes: the
-    // per-element cost is a compare and an add (a wave-wide ballot per element with the group's
-    // bits picked out of it cost three times as much, and these rows are instruction bound)
-    int mine = 0;
+    float c[Q];
+    int cc[Q];
+    // The elements above thr as this row's candidates, if every row of the wave has at most CAP of
+    // them (wave-uniform result).  Candidates per lane, then each lane's first slot by a scan over
+    // the group's lanes: the per-element cost is a compare and an add (a wave-wide ballot per
+    // element with the group's bits picked out of it cost three times as much, and these tiles are
+    // instruction bound).  Nothing is written unless the lists fit.
+    auto compact_above = [&](float thr) -> bool {
+        int mine = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) mine += z[e] > floor_k ? 1 : 0;
-    const int incl = group_scan_incl<G>(mine, gl);
-    int s_final = 1;
-    double S_final = 0.0;
-    bool listed = false;
-    if (__ballot(incl > CAP) == 0ull) {   // incl of a group's last lane is its total
+        for (int e = 0; e < E; ++e) mine += z[e] > thr ? 1 : 0;
+        const int incl = group_scan_incl<G>(mine, gl);
+        if (__ballot(incl > CAP) != 0ull) return false;   // incl of a group's last lane is its total
         const int total = __shfl(incl, lane | (G - 1));
         int off = incl - mine;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const bool in = z[e] > floor_k;
+            const bool in = z[e] > thr;
             if (__ballot(in) != 0ull) {  // wave-uniform
                 if (in) {
                     clist[off] = z[e];
@@ -877,8 +880,6 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
                 off += in ? 1 : 0;
             }
         }
-        float c[Q];
-        int cc[Q];
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -887,21 +888,61 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             cc[q] = (have && list) ? ccols[gl + G * q] : 0;
         }
         wave_lds_sync();
-        solve_core(c, red, CAP, s_final, S_final);
+        return true;
+    };
+
+    int s_final = 1;
+    double S_final = 0.0;
+    float tau = -1.0f, thr_used = floor_k, tau_used = -1.0f;
+    bool fast = compact_above(floor_k);
+    if (!fast) {
+        // Narrow logit distributions.  Michelot starts from the threshold bound of the subset made
+        // of one element per lane, its maximum -- (sum - 1) / count of them is below that subset's
+        // threshold, which is below the row's -- and after every full-width step the candidates
+        // are tried again above the current bound minus the lazy margin (see kLazyMargin: the
+        // list is checked for completeness after the search on it).
+        int cn = lane_mx > -INFINITY ? 1 : 0;
+        float sm = lane_mx > -INFINITY ? lane_mx : 0.0f;
+        red.cs(cn, sm);
+        tau = fmaxf(-1.0f, (sm - 1.0f) / (float)cn);
+        int cnt_prev = 0x7fffffff;
+        for (int pass = 0; pass < kLazyPasses; ++pass) {
+            thr_used = fmaxf(tau - kLazyMargin, floor_k);
+            tau_used = tau;
+            if (compact_above(thr_used)) { fast = true; break; }
+            cn = 0;
+            sm = 0.0f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool in = z[e] > tau;
+                cn += in ? 1 : 0;
+                sm += in ? z[e] : 0.0f;
+            }
+            red.cs(cn, sm);
+            const bool moving = cn < cnt_prev;
+            if (__ballot(moving) == 0ull) break;   // every row of the wave is at its fixed point
+            if (moving) {
+                cnt_prev = cn;
+                tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+            }
+        }
+    }
+    bool listed = false;
+    if (fast) {
+        int m_robust = 0;
+        solve_core(c, red, CAP, s_final, S_final, &m_robust, tau);
+        // a list cut above the floor must be shown to hold everything the oracle could count
+        const bool complete = !(thr_used > floor_k) || lazy_list_is_complete(thr_used, tau_used, m_robust, K);
+        if (__ballot(!complete) != 0ull) fast = false;
+    }
+    if (fast) {
         if (list) {
             const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
             emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live);
             listed = true;
         }
     } else {
-        // full-width search (narrow logit distributions): start Michelot from the threshold bound
-        // of the subset made of one element per lane, its maximum -- (sum - 1) / count of them is
-        // below that subset's threshold, which is below the row's -- instead of from max - 1: for
-        // logits ~ N(0, 0.05^2) at K = 256 that is three full-width passes fewer
-        int cn = lane_mx > -INFINITY ? 1 : 0;
-        float sm = lane_mx > -INFINITY ? lane_mx : 0.0f;
-        red.cs(cn, sm);
-        solve_core(z, red, K, s_final, S_final, nullptr, fmaxf(-1.0f, (sm - 1.0f) / (float)cn));
+        solve_core(z, red, K, s_final, S_final, nullptr, tau);
     }
     const float c_s = (float)S_final - 1.0f;
     const float tau_f = c_s / (float)s_final;
