@@ -376,10 +376,7 @@ struct Sm {
 constexpr double kKktTol = 1e-10;      // accepted residual (any row)
 constexpr double kKktRejudge = 1e-8;   // a starting residual above this voids the convergence decision
 constexpr int kKktPolish = 2;          // refinement steps per attempt
-#ifndef SMLVM_EXP_MAXREB
-#define SMLVM_EXP_MAXREB 1
-#endif
-constexpr int kKktMaxRebuilds = SMLVM_EXP_MAXREB;     // recomputations of the inverse per sample
+constexpr int kKktMaxRebuilds = 1;     // recomputations of the inverse per sample
 constexpr int kKktMaxRejudges = 2;     // re-judgements per sample
 constexpr int kKktPatience = 64;       // passes a re-judged sample gets to converge
 
@@ -644,10 +641,6 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
             if (uni(value <= tau + 1e-9)) {
-#ifdef SMLVM_EXP_NOC7
-                st = SM_CONVERGED;
-                break;
-#endif
                 // C7: accept only an accurate solution of the KKT system
                 const double rho0 = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
                 double rho = rho0;
