@@ -426,14 +426,15 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
 // must be present): Michelot iteration, then the exact edge.
 template <int E, class Red>
 __device__ __forceinline__ void solve_core(const float (&z)[E], Red& red, int nvis, int& s_out,
-                                           double& S_out, int* m_robust = nullptr, float tau0 = -1.0f)
+                                           double& S_out, int* m_robust = nullptr, float tau0 = -1.0f,
+                                           bool at_fixed_point = false)
 {
     // --- Michelot iteration from a lower bound of the threshold (tau >= -1: z_max = 0 after the
     // shift; callers may know a better one).  A start that fp32 rounding put a hair above the true
     // threshold is as good: the edge search below walks down from where the iteration stops.
     float tau = tau0;
     int cnt_prev = 0x7fffffff;
-    for (;;) {
+    while (!at_fixed_point) {   // (uniform over everything `red` spans: the caller ran the iteration)
         int c = 0;
         float s = 0.0f;
 #pragma unroll
@@ -888,6 +889,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     int s_final = 1;
     double S_final = 0.0;
     float tau = -1.0f, thr_used = floor_k, tau_used = -1.0f;
+    bool all_fixed = false;   // wave-uniform: the Michelot iteration below has converged for every row
     bool fast = compact_above(floor_k);
     if (!fast) {
         // Narrow logit distributions.  Michelot starts from the threshold bound of the subset made
@@ -914,7 +916,10 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             }
             red.cs(cn, sm);
             const bool moving = cn < cnt_prev;
-            if (__ballot(moving) == 0ull) break;   // every row of the wave is at its fixed point
+            // every row of the wave is at its fixed point, or one of them is there with more
+            // elements above its threshold than a list holds (a wide support): full-width search
+            all_fixed = __ballot(moving) == 0ull;
+            if (all_fixed || __ballot(!moving && cn > CAP) != 0ull) break;
             if (moving) {
                 cnt_prev = cn;
                 tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
@@ -936,7 +941,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             listed = true;
         }
     } else {
-        solve_core(z, red, K, s_final, S_final, nullptr, tau);
+        solve_core(z, red, K, s_final, S_final, nullptr, tau, all_fixed);
     }
     const float c_s = (float)S_final - 1.0f;
     const float tau_f = c_s / (float)s_final;
