@@ -5,22 +5,36 @@
 
 One "step" = one pass of the hot path over one batch of synthetic logits: sparsemax forward +
 backward over a [rows, K] fp32 matrix resident in HBM (BASELINE.json configs[2], the synthetic
-sweep the metric is quoted on; default 1M rows x K=4096 per GPU, N(0,1) logits).  For N > 1 the
-driver launches this file with torch.distributed.run; rows are sharded per rank with no data-path
-collective (weak scaling: every rank owns `rows` rows), the timed region is bracketed by a barrier
-+ synchronize on both sides and the maximum over ranks is reported.  Rank 0 prints ONE JSON line.
+sweep the metric is quoted on; default 1M rows x K=4096 per GPU, N(0,1) logits).
+
+`--gpus N` with N > 1, started as a plain `python bench.py --gpus N ...`, is the PARENT of the N
+ranks: it touches no GPU, starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 --master-port <free port> bench.py <same flags>` as a child, relays the
+child's JSON line and exits with its status.  A rank (RANK in the environment) binds cuda:LOCAL_RANK,
+joins the RCCL group and refuses to run if WORLD_SIZE differs from --gpus.  Rows are sharded per
+rank with no data-path collective (weak scaling: every rank owns `rows` rows); the timed region is
+bracketed by a barrier + synchronize on both sides and the maximum over ranks is reported; rank 0
+prints ONE JSON line (`ranks_seen`, `rank_checksums_p_dx` and `rccl_version` show that N ranks ran).
 
 Extra objects on that line:
-  roofline      dominant kernel: algorithmic bytes per launch / mean launch time (HIP events on the
-                launch stream inside the timed region) against the 8 TB/s HBM peak
+  roofline      dominant kernel (forward): SURVEY.md 8(d)'s algorithmic bytes per launch (8 K per
+                row) / mean launch time (HIP events on the launch stream inside the timed region)
+                against the 8 TB/s HBM peak; `traffic` = HBM bytes per launch from profiles/traffic.json
+  kernels, fwd_bwd_frac   per launch: the least bytes it has to move (min_traffic below: forward
+                8K + supp + list, list backward 4K + list + one 64-byte sector per support element,
+                ...) / time / 8 TB/s -- no fraction on the line can exceed 1
   cpu_baseline  the CPU oracle (oracle/, plain C, 1 thread) timed on this host on a bounded sample
   cpu_baseline_torch_all_cores  entmax's sort/cumsum algorithm in torch CPU ops on all host threads
-  sweep         fwd+bwd rows/s at the other K of the sweep (256, 65536)
-  compaction    support count / compaction / weighted reduction kernels vs their algorithmic bytes
-  sparsemap     batched active-set solver: samples/s and active-set iterations/s (N > 1: every rank
-                solves 1024 samples at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
+  sweep         SURVEY.md 8(d) S1: K in {256, 4096, 65536} x {N(0,1), N(0,0.05^2), adversarial
+                rows}, 20 launches each, medians
+  compaction    support count / offsets / compaction / weighted reduction kernels through the C ABI
+                on preallocated buffers (median of 20) vs the bytes each has to move
+  sparsemap     batched active-set solver, SURVEY.md 8(d) S5 grid: samples/s, active-set
+                iterations/s, converged / stalled fractions (N > 1: every rank solves 1024 samples
+                at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
   train_steps   one optimisation step of each BASELINE.json model config on synthetic data (N > 1:
-                config 5 with the flat-bucket gradient all-reduce over RCCL)
+                config 5 with the flat-bucket gradient all-reduce over RCCL); config 2 also in the
+                support-only and hoisted-decoder modes
   sparsemap_cpu_baseline  the fp64 C oracle of the solver timed on one host core, same workload
 """
 import argparse
@@ -421,8 +435,8 @@ def train_steps_bench(dev, world, rank):
     BASELINE.json model config on synthetic data of the experiment's shape (bench_models.py)."""
     import bench_models as bm
 
-    def run(model, batch, B, steps=5, warm=2):
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    def run(model, batch, B, steps=5, warm=2, lr=1e-3):
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
         out = None
         for _ in range(warm):
             out = bm.train_step(model, opt, batch, distributed=_dist_on())
@@ -449,6 +463,17 @@ def train_steps_bench(dev, world, rank):
         res["cfg2_signal_game_marg_sparsemax_K256_b64_compact"] = run(m, b, 64)
         m, b = bm.make_signal_game(dev, 64, compact=True, hoist=True)
         res["cfg2_signal_game_marg_sparsemax_K256_b64_compact_hoisted"] = run(m, b, 64)
+        # the sender above collapses to one message per image within the warm-up steps (support 1:
+        # nothing to marginalise, nothing to hoist); the same three steps with the learning rate at
+        # zero keep the random-init sender's support, which is what the decoder modes differ on
+        for tag, kw in (("dense", {}), ("compact", {"compact": True}),
+                        ("compact_hoisted", {"compact": True, "hoist": True})):
+            m, b = bm.make_signal_game(dev, 64, **kw)
+            res[f"cfg2_signal_game_K256_b64_init_support_{tag}"] = run(m, b, 64, lr=0.0)
+        # ... and at a batch where the decoder's work shows above the launch latencies of the step
+        for tag, kw in (("compact", {"compact": True}), ("compact_hoisted", {"compact": True, "hoist": True})):
+            m, b = bm.make_signal_game(dev, 512, **kw)
+            res[f"cfg2_signal_game_K256_b512_init_support_{tag}"] = run(m, b, 512, lr=0.0)
         m, b = bm.make_bitvae(dev, 64, 32, "sparsemap")
         res["cfg4_bitvae_sparsemap_32bits_b64"] = run(m, b, 64)
         m, b = bm.make_bitvae(dev, 64, 32, "sparsemap", fused_decoder=False)

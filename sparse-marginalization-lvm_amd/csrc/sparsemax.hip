@@ -1307,13 +1307,15 @@ __device__ __forceinline__ int64_t wave_row(int lane)
 #ifndef SMLVM_FWD_WPE16
 #define SMLVM_FWD_WPE16 6   // tuning knob (tools/exp_build.sh): waves per SIMD asked for E <= 16 tiles
 #endif
-constexpr int fwd_waves_per_eu(int E) { return E <= 16 ? SMLVM_FWD_WPE16 : (E <= 32 ? 5 : 4); }
+// (with the optional outputs the 64-register tile does not fit 128 VGPRs: 23 spilled registers
+// were 6 KB of scratch per wave, 18 % on top of the launch's HBM traffic -- three waves instead)
+constexpr int fwd_waves_per_eu(int E, bool extra = false) { return E <= 16 ? SMLVM_FWD_WPE16 : (E <= 32 ? 5 : (extra ? 3 : 4)); }
 constexpr int bwd_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 constexpr int bwd_cols_waves_per_eu(int E) { return E <= 32 ? 8 : 3; }
 
 // EXTRA: any of the optional outputs (nnz, tau, entropy) requested.
 template <int G, int E, bool VEC, bool FULL, bool EXTRA>
-__global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E)) void sparsemax_fwd_wave_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) void sparsemax_fwd_wave_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
     int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
     int32_t* __restrict__ cols, int cap, uint32_t* __restrict__ mask, int64_t R, int K)

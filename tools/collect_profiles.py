@@ -22,7 +22,8 @@ d = json.loads(line)
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"])
 print({k: (round(v["ms"], 3), round(v.get("ms_median", 0), 3), round(v.get("hbm_GBps", 0))) for k, v in d["kernels"].items()})
 for k, v in d.get("sweep", {}).items():
-    print(k, round(v["fwd_ms"], 3), round(v["bwd_ms"], 3), round(v["frac_of_hbm_peak"], 3), round(v["mean_support"], 1))
+    print(k, round(v["fwd_ms"], 3), round(v["bwd_ms"], 3), round(v["fwd_frac"], 3), round(v["bwd_frac"], 3),
+          round(v["fwd_bwd_frac"], 3), round(v["mean_support"], 1))
 for k, v in d.get("train_steps", {}).items():
     print(k, round(v["ms_per_step"], 3))
 print(d.get("model_shaped_latency"))

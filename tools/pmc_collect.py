@@ -17,9 +17,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PAT = {"fwd": "sparsemax_fwd", "bwd": "sparsemax_bwd", "count": "support_count_kernel",
-       "count_cols": "support_count_kernel", "compact": "support_compact_kernel",
-       "compact_cols": "support_compact_kernel", "offsets": "scan_", "wlr": "wlr_",
+PAT = {"fwd": "sparsemax_fwd", "bwd": "sparsemax_bwd", "count": "support_count_",
+       "count_cols": "support_count_", "compact": "support_compact_",
+       "compact_cols": "support_compact_", "offsets": "scan_", "wlr": "wlr_",
        "sparsemap": "sparsemap_fwd_kernel"}
 REPS = 3
 
