@@ -83,6 +83,19 @@ int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32
  * ent[r] = -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps), eps = FLT_EPSILON. */
 int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, void* stream);
 
+/* 1.5-entmax over the last axis: third-party entmax.entmax15, the default normaliser of
+ * ExplicitWrapper (lvmhelpers/marg.py:34,46) and the mapping inside Entmax15Loss
+ * (experiments/semi_supervised-vae/train.py:9,314-315).
+ *   p = max(z - tau, 0)^2,  z = x/2 - max(x/2),  tau: sum p = 1
+ *   x [R,K] fp32 -> p [R,K] fp32; nnz [R] int32 = #{p > 0} and tau [R] fp32 (frame of z) nullable.
+ *   bwd: dx = sqrt(p) (dy - sum dy sqrt(p) / sum sqrt(p))       (Entmax15Function.backward)
+ * Floating-point parity with the package's sort/cumsum algorithm (2e-6 on p), not bit parity.
+ * K <= 65536 (SMLVM_ERR_UNSUPPORTED beyond). */
+int smlvm_entmax15_fwd(const float* x, float* p, int32_t* nnz, float* tau, int64_t R, int32_t K,
+                       void* stream);
+int smlvm_entmax15_bwd(const float* dy, const float* p, float* dx, int64_t R, int32_t K,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Kernel 2: non-zero-support stream compaction + probability-weighted loss reduction.
  * Replaces the boolean-mask compaction of lvmhelpers/structmarg.py:113-126 (mask = p.view(-1) > 0,

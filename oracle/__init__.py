@@ -111,6 +111,42 @@ def sparsemax_loss(x, target):
     return loss, grad
 
 
+# ----------------------------------------------------------------------------- entmax15
+def entmax15_fwd(x):
+    """x [R,K] f32 -> (p [R,K] f32, nnz [R] i32, tau [R] f32 in the frame z = x/2 - max(x/2))."""
+    x = _c32(x)
+    R, K = x.shape
+    p = np.empty_like(x)
+    supp = np.empty(R, np.int32)
+    tau = np.empty(R, np.float32)
+    rc = lib().oracle_entmax15_fwd(_ptr(x, _f32p), _ptr(p, _f32p), _ptr(supp, _i32p), _ptr(tau, _f32p),
+                                   ctypes.c_int64(R), ctypes.c_int32(K))
+    assert rc == 0
+    return p, supp, tau
+
+
+def entmax15_bwd(dy, p):
+    dy, p = _c32(dy), _c32(p)
+    R, K = dy.shape
+    dx = np.empty_like(dy)
+    lib().oracle_entmax15_bwd(_ptr(dy, _f32p), _ptr(p, _f32p), _ptr(dx, _f32p), ctypes.c_int64(R),
+                              ctypes.c_int32(K))
+    return dx
+
+
+def entmax15_loss(x, target):
+    """(loss [R] f32, grad [R,K] f32) of the Fenchel-Young 1.5-entmax loss, reduction='none'."""
+    x = _c32(x)
+    t = np.ascontiguousarray(target, np.int64)
+    R, K = x.shape
+    loss = np.empty(R, np.float32)
+    grad = np.empty_like(x)
+    rc = lib().oracle_entmax15_loss(_ptr(x, _f32p), _ptr(t, _i64p), _ptr(loss, _f32p), _ptr(grad, _f32p),
+                                    ctypes.c_int64(R), ctypes.c_int32(K))
+    assert rc == 0
+    return loss, grad
+
+
 # ----------------------------------------------------------------------------- compaction
 def support_compact(p):
     """-> (row_offsets [R+1] i64, rows [N] i32, cols [N] i32, vals [N] f32), row-major."""

@@ -2015,6 +2015,218 @@ static void launch_bwd_stream(const BwdArgs& a)
         else BLOCK<16, 64>(args);                                                               \
     } while (0)
 
+// ------------------------------------------------------------------------------- entmax15
+// 1.5-entmax (the default normaliser of ExplicitWrapper, lvmhelpers/marg.py:46; third-party
+// entmax.entmax15): p = max(z - tau, 0)^2 with z = x/2 - max(x/2) and tau the root of
+// f(tau) = sum max(z - tau, 0)^2 - 1.  The package sorts the row; here the row stays in the same
+// register tiles as sparsemax and tau comes from Newton's iteration started at -1: f is convex and
+// decreasing and f(-1) >= 0 (z_max = 0), so the iterates rise monotonically to the root and never
+// pass it -- every set {z > tau_k} contains the support.  When the step has shrunk below fp32
+// resolution the root is recomputed in closed form (fp64) on the set that is left,
+// tau = mean - sqrt((1 - ss)/c), the package's own formula for that prefix.  Floating-point
+// parity (2e-6 on p), not bit parity: the package's fp32 cumsums are not reproduced.
+constexpr int kE15MaxNewton = 64;
+
+template <int E, class Red>
+__device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_out, float& tau_out)
+{
+    float mx = z[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) mx = fmaxf(mx, z[e]);
+    mx = red.max(mx);
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = (z[e] - mx) * 0.5f;   // padding stays -inf
+    float tau = -1.0f;
+    for (int it = 0; it < kE15MaxNewton; ++it) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float d = fmaxf(z[e] - tau, 0.0f);
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+        const double a = red.sum((double)s1), b = red.sum((double)s2);
+        const float step = (float)((b - 1.0) / (2.0 * a));
+        const bool moving = step > 1e-7f;            // false for NaN rows too
+        if (moving) tau += step;
+        if (__ballot(moving) == 0ull) break;         // every row this wave holds has converged
+    }
+    // closed form on the remaining set (fp64 sums of z and z^2 over {z > tau})
+    int c = 0;
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = z[e] > tau;
+        const double v = in ? (double)z[e] : 0.0;
+        c += in ? 1 : 0;
+        S1 += v;
+        S2 += v * v;
+    }
+    c = red.sum(c);
+    S1 = red.sum(S1);
+    S2 = red.sum(S2);
+    if (c > 0) {
+        const double mean = S1 / (double)c, ss = S2 - (double)c * mean * mean;
+        const double delta = (1.0 - ss) / (double)c;
+        const float tc = (float)(mean - sqrt(delta > 0.0 ? delta : 0.0));
+        tau = tc > tau ? tc : tau;                   // (never below the Newton iterate)
+    }
+    int n = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const float d = fmaxf(z[e] - tau, 0.0f);
+        z[e] = d * d;
+        n += d > 0.0f ? 1 : 0;
+    }
+    nnz_out = red.sum(n);
+    tau_out = tau;
+}
+
+// dx = sqrt(p) (dy - q), q = sum dy sqrt(p) / sum sqrt(p)   (Entmax15Function.backward)
+template <int E, class Red>
+__device__ __forceinline__ void entmax15_bwd_row(float (&g)[E], const float (&y)[E], Red& red)
+{
+    float a = 0.0f, b = 0.0f;
+    float r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        r[e] = sqrtf(y[e]);
+        a = fmaf(g[e], r[e], a);
+        b += r[e];
+    }
+    const double A = red.sum((double)a), B = red.sum((double)b);
+    const float q = (float)(A / B);
+#pragma unroll
+    for (int e = 0; e < E; ++e) g[e] = (g[e] - q) * r[e];
+}
+
+template <int G, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 5 : 4) void entmax15_fwd_wave_kernel(
+    const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ nnz,
+    float* __restrict__ tau, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63, gl = lane % G;
+    int64_t row = wave_row<G>(lane);
+    const bool live = row < R;
+    if (!live) row = R - 1;
+    float z[E];
+    load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
+    WaveRed<G> red;
+    int n;
+    float t;
+    entmax15_row(z, red, n, t);
+    if (live) {
+        store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
+        if (gl == 0) {
+            if (nnz) nnz[row] = n;
+            if (tau) tau[row] = t;
+        }
+    }
+}
+
+template <int NW, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * NW, 4) void entmax15_fwd_block_kernel(
+    const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ nnz,
+    float* __restrict__ tau, int64_t R, int K)
+{
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        float z[E];
+        load_row<E, VEC, FULL, true>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
+        BlockRed<NW> red(lds);
+        int n;
+        float t;
+        entmax15_row(z, red, n, t);
+        store_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, z);
+        if (threadIdx.x == 0) {
+            if (nnz) nnz[row] = n;
+            if (tau) tau[row] = t;
+        }
+        __syncthreads();
+    }
+}
+
+template <int G, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 4 : 2) void entmax15_bwd_wave_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, float* __restrict__ dx, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63, gl = lane % G;
+    int64_t row = wave_row<G>(lane);
+    const bool live = row < R;
+    if (!live) row = R - 1;
+    float g[E], y[E];
+    load_row<E, VEC, FULL>(p + row * K, K, gl, G, y, 0.0f);
+    load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+    WaveRed<G> red;
+    entmax15_bwd_row(g, y, red);
+    if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
+}
+
+template <int NW, int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * NW) void entmax15_bwd_block_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, float* __restrict__ dx, int64_t R, int K)
+{
+    __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+        float g[E], y[E];
+        load_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, y, 0.0f);
+        load_row<E, VEC, FULL, true>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
+        BlockRed<NW> red(lds);
+        entmax15_bwd_row(g, y, red);
+        store_row<E, VEC, FULL, true>(dx + row * K, K, threadIdx.x, 64 * NW, g);
+        __syncthreads();
+    }
+}
+
+struct E15Args {
+    const float* in0;     // x (forward) / dy (backward)
+    const float* in1;     // p (backward)
+    float* out;           // p (forward) / dx (backward)
+    int32_t* nnz;
+    float* tau;
+    int64_t R;
+    int K;
+    hipStream_t st;
+    bool vec;
+};
+
+#define SMLVM_E15_MODES(GO, A, E)                                                \
+    do {                                                                         \
+        const bool full = a.vec && a.K == A * E;                                 \
+        if (!a.vec) GO<A, E, false, false>(a);                                   \
+        else if (full) GO<A, E, true, true>(a);                                  \
+        else GO<A, E, true, false>(a);                                           \
+    } while (0)
+
+template <int G, int E, bool VEC, bool FULL>
+static void e15_fwd_wave_go(const E15Args& a)
+{
+    hipLaunchKernelGGL((entmax15_fwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
+                       dim3(64 * kWavesPerBlock), 0, a.st, a.in0, a.out, a.nnz, a.tau, a.R, a.K);
+}
+template <int NW, int E, bool VEC, bool FULL>
+static void e15_fwd_block_go(const E15Args& a)
+{
+    hipLaunchKernelGGL((entmax15_fwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)), dim3(64 * NW),
+                       0, a.st, a.in0, a.out, a.nnz, a.tau, a.R, a.K);
+}
+template <int G, int E, bool VEC, bool FULL>
+static void e15_bwd_wave_go(const E15Args& a)
+{
+    hipLaunchKernelGGL((entmax15_bwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
+                       dim3(64 * kWavesPerBlock), 0, a.st, a.in0, a.in1, a.out, a.R, a.K);
+}
+template <int NW, int E, bool VEC, bool FULL>
+static void e15_bwd_block_go(const E15Args& a)
+{
+    hipLaunchKernelGGL((entmax15_bwd_block_kernel<NW, E, VEC, FULL>), dim3(block_grid(a.R)), dim3(64 * NW),
+                       0, a.st, a.in0, a.in1, a.out, a.R, a.K);
+}
+template <int A, int E> static void launch_e15_fwd_wave(const E15Args& a) { SMLVM_E15_MODES(e15_fwd_wave_go, A, E); }
+template <int A, int E> static void launch_e15_fwd_block(const E15Args& a) { SMLVM_E15_MODES(e15_fwd_block_go, A, E); }
+template <int A, int E> static void launch_e15_bwd_wave(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_wave_go, A, E); }
+template <int A, int E> static void launch_e15_bwd_block(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_block_go, A, E); }
+
 }  // namespace smlvm
 
 using namespace smlvm;
@@ -2092,5 +2304,30 @@ extern "C" int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, v
     if (!p || !ent) return SMLVM_ERR_INVALID;
     hipLaunchKernelGGL(entropy_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, p, ent, R, K);
+    return check_launch();
+}
+
+extern "C" int smlvm_entmax15_fwd(const float* x, float* p, int32_t* nnz, float* tau, int64_t R,
+                                  int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    if (R == 0) return SMLVM_OK;
+    if (!x || !p) return SMLVM_ERR_INVALID;
+    E15Args a{x, nullptr, p, nnz, tau, R, K, (hipStream_t)stream, (K % 4 == 0) && aligned16(x) && aligned16(p)};
+    SMLVM_DISPATCH(launch_e15_fwd_wave, launch_e15_fwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_entmax15_bwd(const float* dy, const float* p, float* dx, int64_t R, int32_t K,
+                                  void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (K > 65536) return SMLVM_ERR_UNSUPPORTED;
+    if (R == 0) return SMLVM_OK;
+    if (!dy || !p || !dx) return SMLVM_ERR_INVALID;
+    E15Args a{dy, p, dx, nullptr, nullptr, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx)};
+    SMLVM_DISPATCH(launch_e15_bwd_wave, launch_e15_bwd_block, a);
     return check_launch();
 }

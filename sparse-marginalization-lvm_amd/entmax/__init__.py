@@ -1,52 +1,13 @@
 """Stand-in for the third-party ``entmax`` package on machines that do not have it, so that
 ``from entmax import sparsemax, entmax15, SparsemaxLoss, Entmax15Loss`` in the reference's
-experiment scripts (experiments/semi_supervised-vae/train.py:9) resolves.  ``sparsemax`` and
-``SparsemaxLoss`` are the gfx950 kernels of this repository; ``entmax15`` / ``Entmax15Loss`` are
-plain PyTorch restatements of the published algorithm (Peters et al. 2019), kept only for API
-completeness (no experiment script selects them: lvmhelpers/utils.py:36-39)."""
+experiment scripts (experiments/semi_supervised-vae/train.py:9) resolves.  ``sparsemax``,
+``entmax15`` and the two Fenchel-Young losses run on the gfx950 kernels of this repository
+(``smlvm_sparsemax_*``, ``smlvm_entmax15_*``); the published algorithms they follow are restated
+in ``oracle/sparsemax_oracle.c`` and ``oracle/entmax15_oracle.c``."""
 import torch
 import torch.nn as nn
 
-from lvmhelpers.functional import sparsemax  # noqa: F401
-
-
-def _entmax15_fwd(X, dim):
-    X = X / 2
-    X = X - X.max(dim=dim, keepdim=True)[0]
-    Xs, _ = torch.sort(X, dim=dim, descending=True)
-    d = X.shape[dim]
-    shape = [1] * X.dim()
-    shape[dim] = -1
-    rho = torch.arange(1, d + 1, device=X.device, dtype=X.dtype).view(shape)
-    mean = Xs.cumsum(dim) / rho
-    mean_sq = (Xs ** 2).cumsum(dim) / rho
-    ss = rho * (mean_sq - mean ** 2)
-    delta = (1 - ss) / rho
-    tau = mean - torch.sqrt(torch.clamp(delta, 0))
-    support = (tau <= Xs).sum(dim=dim, keepdim=True)
-    tau_star = tau.gather(dim, support - 1)
-    return torch.clamp(X - tau_star, min=0) ** 2
-
-
-class _Entmax15(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, X, dim):
-        Y = _entmax15_fwd(X, dim)
-        ctx.dim = dim
-        ctx.save_for_backward(Y)
-        return Y
-
-    @staticmethod
-    def backward(ctx, dY):
-        (Y,) = ctx.saved_tensors
-        gppr = Y.sqrt()
-        dX = dY * gppr
-        q = dX.sum(ctx.dim, keepdim=True) / gppr.sum(ctx.dim, keepdim=True)
-        return dX - q * gppr, None
-
-
-def entmax15(X, dim=-1):
-    return _Entmax15.apply(X, dim)
+from lvmhelpers.functional import entmax15, sparsemax  # noqa: F401
 
 
 class _SparsemaxLossFn(torch.autograd.Function):
@@ -71,7 +32,7 @@ class _SparsemaxLossFn(torch.autograd.Function):
 class _Entmax15LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, target):
-        p = _entmax15_fwd(X.detach(), -1)
+        p = entmax15(X.detach(), dim=-1)
         loss = (1 - (p * torch.sqrt(p)).sum(dim=1)) / 0.75
         p = p.clone()
         p.scatter_add_(1, target.unsqueeze(1), torch.full_like(p, -1))

@@ -17,7 +17,7 @@ _lib = None
 ABI_SYMBOLS = [
     "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error",
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
-    "smlvm_sparsemax_bwd_cols", "smlvm_entropy",
+    "smlvm_sparsemax_bwd_cols", "smlvm_entropy", "smlvm_entmax15_fwd", "smlvm_entmax15_bwd",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
     "smlvm_support_offsets_noalloc",
     "smlvm_sparsemax_support_mask_bytes", "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
@@ -168,6 +168,30 @@ def entropy(p):
     with torch.cuda.device(p.device):
         _check(lib().smlvm_entropy(_p(p), _p(out), _i64(R), _i32(K), _stream()), "smlvm_entropy")
     return out
+
+
+def entmax15_fwd(x, want_nnz=False, want_tau=False):
+    """x [R,K] -> (p, nnz | None, tau | None); 1.5-entmax over the last axis."""
+    x = _need_gpu(x, torch.float32, "x")
+    R, K = x.shape
+    p = torch.empty_like(x)
+    nnz = torch.empty(R, dtype=torch.int32, device=x.device) if want_nnz else None
+    tau = torch.empty(R, dtype=torch.float32, device=x.device) if want_tau else None
+    with torch.cuda.device(x.device):
+        _check(lib().smlvm_entmax15_fwd(_p(x), _p(p), _p(nnz), _p(tau), _i64(R), _i32(K), _stream()),
+               "smlvm_entmax15_fwd")
+    return p, nnz, tau
+
+
+def entmax15_bwd(dy, p):
+    dy = _need_gpu(dy, torch.float32, "dy")
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    dx = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_entmax15_bwd(_p(dy), _p(p), _p(dx), _i64(R), _i32(K), _stream()),
+               "smlvm_entmax15_bwd")
+    return dx
 
 
 # ----------------------------------------------------------------------------------- compaction

@@ -25,6 +25,22 @@ class _Sparsemax(torch.autograd.Function):
         return dx.view(dy.shape)
 
 
+class _Entmax15(torch.autograd.Function):
+    """Row-wise 1.5-entmax over the last dim (replaces entmax.entmax15; marg.py:46)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        shape = x.shape
+        p, _, _ = _native.entmax15_fwd(x.reshape(-1, shape[-1]))
+        ctx.save_for_backward(p)
+        return p.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (p,) = ctx.saved_tensors
+        return _native.entmax15_bwd(dy.reshape(p.shape).contiguous(), p).view(dy.shape)
+
+
 class _SparsemaxEntropy(torch.autograd.Function):
     """Fused sparsemax + Shannon entropy (marg.py:51-52): one forward kernel, one backward kernel."""
 
@@ -148,6 +164,15 @@ def sparsemax(X, dim=-1):
     if p.dim() == 2:
         _tag_support(p, cols)
     return p
+
+
+def entmax15(X, dim=-1):
+    """entmax.entmax15 replacement: p = max(X/2 - tau, 0)^2 along `dim`, sum p = 1."""
+    if dim < 0:
+        dim += X.dim()
+    if dim != X.dim() - 1:
+        return _Entmax15.apply(X.transpose(dim, -1).contiguous()).transpose(dim, -1)
+    return _Entmax15.apply(X.contiguous())
 
 
 SUPPORT_ATTR = "_smlvm_support_cols"

@@ -1,0 +1,104 @@
+"""GPU parity of the 1.5-entmax kernels (smlvm_entmax15_fwd/_bwd, through the C ABI) against the
+CPU oracle.  Floating point: the kernel finds tau by Newton + a closed form in fp64, the package by
+fp32 sort/cumsum; tolerance 2e-6 absolute on p (values in [0, 1]) and 2e-5 relative on dx."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(R, K, sigma, seed):
+    rng = np.random.default_rng(seed)
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    x[0] = 0.25
+    if R > 2 and K > 1:
+        x[1] = -2.0
+        x[1, K // 3] = 5.0
+        x[2] = np.round(x[2] * 2) / 2
+    return x
+
+
+@pytest.mark.parametrize("R,K,sigma", [(5, 1, 1.0), (64, 10, 1.0), (33, 31, 1.0), (64, 100, 1.0), (64, 256, 1.0),
+                                       (64, 256, 0.05), (9, 257, 1.0), (40, 512, 3.0), (17, 1000, 1.0),
+                                       (12, 2048, 1.0), (20, 4096, 1.0), (7, 4097, 1.0), (6, 10000, 1.0),
+                                       (5, 16384, 0.2), (4, 32768, 1.0), (3, 65536, 1.0), (3, 50001, 1.0)])
+def test_fwd_bwd_match_oracle(dev, oracle_mod, R, K, sigma):
+    from lvmhelpers import _native
+    x = _rows(R, K, sigma, R * 31 + K)
+    p_ref, nnz_ref, tau_ref = oracle_mod.entmax15_fwd(x)
+    xt = torch.from_numpy(x).to(dev)
+    p, nnz, tau = _native.entmax15_fwd(xt, want_nnz=True, want_tau=True)
+    pn = p.cpu().numpy()
+    assert np.abs(pn - p_ref).max() <= 2e-6
+    assert np.abs(pn.sum(1) - 1.0).max() <= 2e-6 * max(1.0, np.sqrt(K) / 8)
+    assert np.abs(tau.cpu().numpy() - tau_ref).max() <= 1e-6
+    # the support may differ from the oracle's only by elements within rounding of tau
+    z = x / 2 - (x / 2).max(1, keepdims=True)
+    unsure = np.abs(z - tau_ref[:, None]) <= 2e-6
+    assert np.all(((pn > 0) == (p_ref > 0)) | unsure)
+    assert np.array_equal(nnz.cpu().numpy(), (pn > 0).sum(1))
+    dy = np.random.default_rng(K).standard_normal(x.shape).astype(np.float32)
+    dx = _native.entmax15_bwd(torch.from_numpy(dy).to(dev), p).cpu().numpy()
+    dx_ref = oracle_mod.entmax15_bwd(dy, pn)
+    assert np.abs(dx - dx_ref).max() <= 2e-5 * max(1.0, np.abs(dx_ref).max())
+
+
+def test_autograd_and_module_paths(dev, oracle_mod):
+    """functional.entmax15 / the entmax shim / ExplicitWrapper(normalizer='entmax') run the kernels;
+    any `dim`; Entmax15Loss value and gradient."""
+    import entmax
+    from lvmhelpers import functional as F_
+    from lvmhelpers.marg import ExplicitWrapper
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((6, 20, 12)).astype(np.float32)
+    for dim in (-1, 1, 0):
+        xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+        p = F_.entmax15(xt, dim=dim)
+        w = torch.from_numpy(rng.standard_normal(x.shape).astype(np.float32)).to(dev)
+        (p * w).sum().backward()
+        xm = np.moveaxis(x, dim, -1)
+        p_ref, _, _ = oracle_mod.entmax15_fwd(xm.reshape(-1, xm.shape[-1]))
+        assert np.abs(np.moveaxis(p.detach().cpu().numpy(), dim, -1).reshape(p_ref.shape) - p_ref).max() <= 2e-6
+        dref = oracle_mod.entmax15_bwd(np.moveaxis(w.cpu().numpy(), dim, -1).reshape(p_ref.shape), p_ref)
+        got = np.moveaxis(xt.grad.cpu().numpy(), dim, -1).reshape(p_ref.shape)
+        assert np.abs(got - dref).max() <= 3e-5
+    assert entmax.entmax15 is F_.entmax15
+    x2 = rng.standard_normal((64, 10)).astype(np.float32)
+    t = rng.integers(0, 10, 64)
+    xt = torch.from_numpy(x2).to(dev).requires_grad_(True)
+    loss = entmax.Entmax15Loss(reduction="none")(xt, torch.from_numpy(t).to(dev))
+    loss.sum().backward()
+    l_ref, g_ref = oracle_mod.entmax15_loss(x2, t)
+    assert np.allclose(loss.detach().cpu().numpy(), l_ref, rtol=1e-5, atol=2e-6)
+    assert np.abs(xt.grad.cpu().numpy() - g_ref).max() <= 2e-6
+    enc = ExplicitWrapper(torch.nn.Identity())          # default normaliser: entmax15 (marg.py:34)
+    sample, distr, ent = enc(torch.from_numpy(x2).to(dev))
+    assert np.abs(distr.cpu().numpy() - oracle_mod.entmax15_fwd(x2)[0]).max() <= 2e-6
+    assert torch.equal(sample, torch.from_numpy(x2).to(dev).argmax(-1))
+    assert np.allclose(ent.cpu().numpy(), oracle_mod.entropy(distr.cpu().numpy()), atol=1e-5)
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json's sweep shape: sum p = 1, p >= 0, p = max(z - tau, 0)^2, and the backward is
+    zero outside the support and for a constant dy."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.empty(1 << 16, 4096, device=dev).normal_(0.0, 1.0, generator=g)
+    p, nnz, tau = _native.entmax15_fwd(x, want_nnz=True, want_tau=True)
+    assert float((p.sum(1) - 1).abs().max()) <= 5e-6
+    z = x / 2 - (x / 2).max(1, keepdim=True)[0]
+    assert float((torch.clamp(z - tau[:, None], min=0) ** 2 - p).abs().max()) <= 1e-6
+    assert torch.equal(nnz, (p > 0).sum(1).to(torch.int32))
+    dy = torch.empty_like(x).normal_(0.0, 1.0, generator=g)
+    dx = _native.entmax15_bwd(dy, p)
+    assert bool(((dx != 0) <= (p > 0)).all())               # zero outside the support
+    # J = diag(s) - s s^T / sum(s), s = sqrt(p): J 1 = 0 => dx for dy = const is 0
+    dx1 = _native.entmax15_bwd(torch.ones_like(x), p)
+    assert float(dx1.abs().max()) <= 1e-5
+
+
+def test_unsupported_width(dev):
+    from lvmhelpers import _native
+    with pytest.raises(_native.NativeError):
+        _native.entmax15_fwd(torch.zeros(1, 65540, device=dev))
