@@ -156,7 +156,8 @@ def min_traffic(K, cap, cols, supp, has_mask):
                      (+ 512 B for a row that leaves a support mask)
       backward       row with a list:  write dx, read list + supp, one 64 B sector of dy per listed
                                        column: 4K + 4 cap + 4 + 64 s
-                     row with a mask:  4K + 512 + 64 + 4 + 64 s
+                     row with a mask:  4K + 512 + 64 + 4 + 64 s  (1024 < K <= 4096);
+                                       8K + 2G + 64 + 4 for 32 < K <= 1024 (dy streamed, G lanes per row)
                      no list, s <= gather_max: read p, write dx, gather dy: 8K + 4 + 64 s
                      otherwise: stream dy and p, write dx: 12K + 4
     These are the denominators of every `frac` below (never the 20 K model, which the list backward
@@ -165,13 +166,23 @@ def min_traffic(K, cap, cols, supp, has_mask):
     head = cols[:, 0]
     s = supp.to(torch.float64)
     listed = head >= -1
-    masked = (head == -3) & (supp <= gather_max(K)) if has_mask else torch.zeros_like(listed)
+    small = 32 < K <= 1024    # 16-register tiles: every row leaves a pattern of 2 G bytes
+    pat = 2.0 * (8 if K <= 128 else 16 if K <= 256 else 32 if K <= 512 else 64)
+    if not has_mask:
+        masked = torch.zeros_like(listed)
+    elif small:
+        masked = head == -3
+    else:
+        masked = (head == -3) & (supp <= gather_max(K))
     gath = ~listed & ~masked & (supp <= gather_max(K))
     stream = ~listed & ~masked & ~gath
     n_masked_fwd = int((head == -3).sum().item()) if has_mask else 0
-    fwd = R * (8.0 * K + 4 + 4 * cap) + 512.0 * n_masked_fwd
+    fwd = R * (8.0 * K + 4 + 4 * cap) + (pat * R if (small and has_mask) else 512.0 * n_masked_fwd)
+    # a pattern row of a 16-register tile streams dy: 8K + pattern + list head + supp
+    masked_row = (8.0 * K + pat + 64 + 4) if small else (4.0 * K + 512 + 64 + 4)
+    masked_sectors = 0.0 if small else 64.0 * float(s[masked].sum().item())
     bwd = (float(listed.sum().item()) * (4.0 * K + 4 * cap + 4) + 64.0 * float(s[listed].sum().item())
-           + float(masked.sum().item()) * (4.0 * K + 512 + 64 + 4) + 64.0 * float(s[masked].sum().item())
+           + float(masked.sum().item()) * masked_row + masked_sectors
            + float(gath.sum().item()) * (8.0 * K + 4) + 64.0 * float(s[gath].sum().item())
            + float(stream.sum().item()) * (12.0 * K + 4))
     return {"fwd": fwd, "bwd": bwd,

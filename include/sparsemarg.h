@@ -66,10 +66,13 @@ int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_siz
  *   columns): the backward then reads p for that row exactly like smlvm_sparsemax_bwd.
  *   support_cols may be NULL (then these are the plain entry points).
  *   support_mask (nullable; smlvm_sparsemax_support_mask_bytes(R, K) bytes, 0 unless
- *   1024 < K <= 4096): for rows with more than cap non-zeros the forward leaves the non-zero
- *   pattern there as a bitmap (layout private to the library) and marks the row -3 instead of -2;
- *   the backward then gathers dy at those bits and still does not read p (rows with up to 96
- *   non-zeros).  Pass the same buffer to both calls, or NULL to both. */
+ *   32 < K <= 4096 -- a row of at most 32 entries always fits its list): non-zero patterns as
+ *   bitmaps (layout private to the library).  1024 < K <= 4096: rows with more than cap non-zeros
+ *   leave their pattern (512 B) and are marked -3 instead of -2; the backward gathers dy at those
+ *   bits and does not read p (rows with up to 96 non-zeros).  32 < K <= 1024: EVERY row leaves its
+ *   pattern (2 bytes per lane of its lane group: 16 B ... 128 B per row), rows with more than cap
+ *   non-zeros are marked -3, and the backward streams dy for them without reading p.  Pass the
+ *   same buffer, with the same R and K, to both calls, or NULL to both. */
 size_t smlvm_sparsemax_support_mask_bytes(int64_t R, int32_t K);
 int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
                              float* entropy, int32_t* support_cols, int32_t cap,

@@ -828,9 +828,9 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
 // takes the full-width search.
 template <int E, int G, bool VEC>
 __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand, int K,
-                                                    int& supp, float& tau_out,
+                                                    int& supp, float& tau_out, int& n_listed,
                                                     int32_t* list = nullptr, int cap = 0,
-                                                    bool live = true)
+                                                    bool live = true, int mark = kColsOverflow)
 {
     const float floor_k = cand_floor(K);
     static_assert(G < 64, "lane groups inside one wave");
@@ -937,7 +937,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     if (fast) {
         if (list) {
             const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-            emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live);
+            n_listed = emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live, mark);
             listed = true;
         }
     } else {
@@ -1324,7 +1324,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
     const int gl = lane % G;
     int64_t row = wave_row<G>(lane);
     constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
-    const int mark = (MASKS && mask != nullptr) ? kColsMask : kColsOverflow;
+    constexpr bool MASKS16 = VEC && (E == 16);   // 32 < K <= 1024: 16 bits per lane, see below
+    const int mark = ((MASKS || MASKS16) && mask != nullptr) ? kColsMask : kColsOverflow;
     const bool live = row < R;
     if (!live) row = R - 1;  // keep every lane busy (DPP needs whole groups); results discarded
     constexpr bool CAND = (G == 64);
@@ -1341,7 +1342,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
     int n_listed = 0;   // #{p > 0} as counted by whoever wrote (or gave up on) the row's list
     if constexpr (GCAND)
         listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, K, s, t,
-                                                list, cap, live);
+                                                n_listed, list, cap, live, mark);
     else
         listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
                                                 K, s, t, n_listed, list, cap, live, mark);
@@ -1360,6 +1361,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
             }
             uint2* mrow = reinterpret_cast<uint2*>(mask + row * kMaskWordsPerRow);
             mrow[lane] = make_uint2(mlo, mhi);
+        }
+    }
+    if constexpr (MASKS16) {
+        // Tiles of 16 registers: EVERY row leaves its pattern (16 bits per lane, 2 G bytes per row:
+        // 32 B at K = 256), so a wave of the backward that holds a row without a list can take all
+        // of its rows from the patterns and never reads p; the rows that overflow their list are
+        // marked kColsMask exactly as above.
+        if (cols && mask && live) {
+            uint32_t bits = 0u;
+#pragma unroll
+            for (int e = 0; e < E; ++e) bits |= (z[e] > 0.0f ? 1u : 0u) << e;
+            reinterpret_cast<uint16_t*>(mask)[row * G + gl] = (uint16_t)bits;
         }
     }
     if (live) {
@@ -1475,6 +1488,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
             for (int e = 0; e < E; ++e) a[e] = 0.0f;
             bwd_row_gather_bits<E, VEC>(dy + row * K, gl, G, a, m.x, m.y, s, red);
             if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+            return;
+        }
+    }
+    if constexpr (VEC && E == 16) {
+        // some row of this wave has no list but the forward left every row's pattern: dy is
+        // streamed (a row is at most 4 KB), p is not read; same sum in the same order as bwd_row
+        if (mask && __ballot(head == kColsMask) != 0ull && __ballot(head == kColsOverflow) == 0ull) {
+            const uint32_t bits = reinterpret_cast<const uint16_t*>(mask)[row * G + gl];
+            float g[E];
+            load_row<E, VEC, FULL>(dy + row * K, K, gl, G, g, 0.0f);
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc += ((bits >> e) & 1u) ? (double)g[e] : 0.0;
+            acc = red.sum(acc);
+            const float v = (float)acc / (float)s;
+#pragma unroll
+            for (int e = 0; e < E; ++e) g[e] = ((bits >> e) & 1u) ? (g[e] - v) : 0.0f;
+            if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
             return;
         }
     }
@@ -2246,7 +2277,11 @@ extern "C" int smlvm_sparsemax_fwd(const float* x, float* p, int32_t* supp_size,
 
 extern "C" size_t smlvm_sparsemax_support_mask_bytes(int64_t R, int32_t K)
 {
-    if (R <= 0 || K <= 1024 || K > 4096) return 0;
+    if (R <= 0 || K <= 32 || K > 4096) return 0;
+    if (K <= 1024) {   // 16-register tiles: 16 bits per lane of the row's lane group (SMLVM_DISPATCH)
+        const int lanes = K <= 128 ? 8 : (K <= 256 ? 16 : (K <= 512 ? 32 : 64));
+        return (size_t)R * lanes * sizeof(uint16_t);
+    }
     return (size_t)R * kMaskWordsPerRow * sizeof(uint32_t);
 }
 
@@ -2261,7 +2296,7 @@ extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap,
-              (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
+              (support_cols && K > 32 && K <= 4096) ? support_mask : nullptr};
     if (K > 65536) launch_fwd_stream(a);
     else SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
@@ -2291,7 +2326,7 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,
               (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx),
-              support_cols, cap, (support_cols && K > 1024 && K <= 4096) ? support_mask : nullptr};
+              support_cols, cap, (support_cols && K > 32 && K <= 4096) ? support_mask : nullptr};
     if (K > 65536) launch_bwd_stream(a);
     else SMLVM_DISPATCH(launch_bwd_wave, launch_bwd_block, a);
     return check_launch();

@@ -471,6 +471,51 @@ def test_support_mask_backward(dev, oracle_mod, K, sigma):
     assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols2, p, supp), dx_p)
 
 
+@pytest.mark.parametrize("R,K,sigma", [(301, 256, 0.05), (64, 256, 0.02), (77, 128, 0.05), (50, 64, 0.02),
+                                       (99, 512, 0.05), (130, 1000, 0.05), (65, 1024, 0.03), (40, 36, 0.01),
+                                       (123, 256, 1.0), (33, 260, 0.05)])
+def test_support_patterns_of_short_rows(dev, oracle_mod, R, K, sigma):
+    """32 < K <= 1024 (tiles of 16 registers, several rows per wave up to K = 512): with the mask
+    buffer every row leaves its non-zero pattern; rows that overflow their list are marked -3, the
+    others keep their lists; a wave of the backward that holds a -3 row takes all of its rows from
+    the patterns and streams dy without reading p.  dx bit-identical to the p-based backward."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(R * 13 + K)
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    x[::5] *= 40                      # short supports in between: mixed waves
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    xt, dyt = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev)
+    p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
+    assert mask is not None and np.array_equal(p.cpu().numpy(), p_ref)
+    head = cols[:, 0].cpu().numpy()
+    nnz = (p_ref > 0).sum(1)
+    cap = cols.shape[1]
+    assert np.all(head[nnz > cap] == -3) and np.all(head[nnz <= cap] >= 0)
+    if sigma < 1.0:
+        assert (nnz > cap).any() and (nnz <= cap).any()
+    dx_mask = _native.sparsemax_bwd_cols(dyt, cols, p, supp, mask)
+    dx_p = _native.sparsemax_bwd(dyt, p, supp)
+    assert torch.equal(dx_mask, dx_p)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    assert np.all(np.abs(dx_mask.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+    # p is not read for rows marked -3: poison it there
+    poisoned = p.clone()
+    poisoned[torch.from_numpy(nnz > cap).to(dev)] = float("nan")
+    assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols, poisoned, supp, mask), dx_mask)
+    # the lists of the rows that kept them are what the plain forward writes
+    _, _, _, _, _, cols2 = _native.sparsemax_fwd(xt, want_cols=True)
+    keep = torch.from_numpy(nnz <= cap).to(dev)
+    assert torch.equal(cols[keep], cols2[keep])
+    assert np.all(cols2[:, 0].cpu().numpy()[nnz > cap] == -2)
+    assert torch.equal(_native.sparsemax_bwd_cols(dyt, cols2, p, supp), dx_p)
+    # compaction fed with the tagged lists: -3 rows are scanned from p
+    off0, rows0, cols0, vals0 = _native.support_compact(p)
+    off1, rows1, cols1, vals1 = _native.support_compact(p, support_cols=cols)
+    assert torch.equal(off0, off1) and torch.equal(cols0, cols1) and torch.equal(vals0, vals1)
+
+
 @pytest.mark.parametrize("kind", ["normal", "narrow", "verynarrow", "adversarial"])
 @pytest.mark.parametrize("R,K", [(3, 65540), (2, 100000), (2, 131072), (2, 200001), (1, 262144)])
 def test_rows_wider_than_a_workgroup(dev, oracle_mod, R, K, kind):
