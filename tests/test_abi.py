@@ -79,7 +79,10 @@ def test_argument_validation_without_gpu(lib):
     lib.smlvm_sparsemax_support_mask_bytes.restype = ctypes.c_size_t
     assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(4096)) == 10 * 512
     assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(1025)) == 10 * 512
-    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(1024)) == 0
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(1024)) == 10 * 128   # 2 B x 64 lanes
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(256)) == 10 * 32
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(33)) == 10 * 16
+    assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(32)) == 0
     assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(4100)) == 0
     assert lib.smlvm_support_compact_cols(null, null, i32(0), null, null, null, null, i64(0), i32(4), null) == 0
     assert lib.smlvm_support_compact_cols(one, one, i32(65), one, null, null, null, i64(3), i32(4), null) == -1
