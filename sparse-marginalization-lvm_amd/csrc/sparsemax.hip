@@ -639,7 +639,7 @@ __device__ __forceinline__ int emit_cols_from_candidates(const float (&c)[Q], co
 // z: in = raw row (padding = -inf), out = p.  Returns supp_size, tau (shifted frame).
 // NW = waves holding the row (1: a lane group of one wave; then G < 64 skips the candidate path).
 // cand: LDS, NW == 1: 2*kCandCap words private to this wave (values, columns); NW > 1: NW*64
-// floats + NW ints + NW*64 ints (values, counts, columns).
+// floats + NW ints + NW*64 ints + NW*64 floats (values, counts, columns, lane maxima).
 // list != null: the row's support list is wanted; returns true if it was written
 // here (from the candidates; n_listed = the #{p > 0} it saw), false if the caller has to scan the
 // registers.
@@ -722,11 +722,19 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             float thr = floor_k, tau = -1.0f;
             bool first = true;
             int cnt_prev = 0x7fffffff, passes = 0;
+            // every lane's maximum, parked for the refinement of the bound after a first failure
+            float* lmx = cand + 2 * NW * 64 + NW;
+            lmx[threadIdx.x] = lane_mx;
             for (;;) {
-                const int n_w = compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
-                                                           ccols ? ccols + wave * 64 : nullptr,
-                                                           VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
-                                                           VEC ? 256 * NW : 64 * NW);
+                // a wave in which every lane holds an element above the cut has at least 64 of them:
+                // its 64-entry list would have no room to spare, so it does not even try (narrow
+                // logit distributions: saves the 64 ballots of a compaction that cannot succeed)
+                const bool crowded = first && __ballot(lane_mx > thr) == ~0ull;
+                const int n_w = crowded ? 65
+                                        : compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
+                                                                     ccols ? ccols + wave * 64 : nullptr,
+                                                                     VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
+                                                                     VEC ? 256 * NW : 64 * NW);
                 if (lane == 0) cnt[wave] = n_w;
                 __syncthreads();
                 int total = 0, worst = 0;
@@ -758,16 +766,29 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 }
                 __syncthreads();  // the lists are rewritten by the next attempt / the next row
                 if (fast) { thr_used = thr; tau_used = tau; break; }
-                if (first) {   // first failure: the best wave-local subset bound, then retry
+                if (first) {
+                    // first failure: the threshold of the subset made of all 64 NW lane maxima is a
+                    // lower bound of the row's.  Every wave runs that Michelot iteration on its own
+                    // copy of the maxima (NW values per lane out of LDS, the same values in the same
+                    // lanes and therefore the same bits in every wave): no pass over the registers
+                    // and no workgroup barrier (the workgroup-wide version of this loop cost a
+                    // barrier per step, 5-6 of them per row).
                     first = false;
-                    tau = red.max(subset_bound(lane_mx));
-                    // ... refined on the subset of all 64 NW lane maxima (one value per lane: block
-                    // reductions, but no pass over the registers)
+                    float v[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) v[w] = lmx[w * 64 + lane];
+                    WaveRed<64> wred;
+                    tau = -1.0f;
                     for (int cp = 0x7fffffff;;) {
-                        const bool in = lane_mx > tau;
-                        int cn = in ? 1 : 0;
-                        float sm = in ? lane_mx : 0.0f;
-                        red.cs(cn, sm);
+                        int cn = 0;
+                        float sm = 0.0f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            const bool in = v[w] > tau;
+                            cn += in ? 1 : 0;
+                            sm += in ? v[w] : 0.0f;
+                        }
+                        wred.cs(cn, sm);
                         if (cn >= cp) break;
                         cp = cn;
                         tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
@@ -1398,7 +1419,7 @@ __global__ __launch_bounds__(64 * NW, 4) void sparsemax_fwd_block_kernel(
     int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    __shared__ float cand[2 * NW * 64 + NW];
+    __shared__ float cand[3 * NW * 64 + NW];   // candidate values, counts, columns, lane maxima
     // XCD-aware row order for the small workgroups (K = 16384 forward 1.45 -> 1.37 ms; neutral at
     // NW = 8, a loss at NW = 16 where one workgroup fills the CU)
     for (int64_t row = xcd_block<(NW <= 4)>(); row < R; row += gridDim.x) {
