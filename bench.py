@@ -156,7 +156,8 @@ def min_traffic(K, cap, cols, supp, has_mask):
                      (+ 512 B for a row that leaves a support mask)
       backward       row with a list:  write dx, read list + supp, one 64 B sector of dy per listed
                                        column: 4K + 4 cap + 4 + 64 s
-                     row with a mask:  4K + 512 + 64 + 4 + 64 s  (1024 < K <= 4096);
+                     row with a mask:  4K + 512 + 64 + 4 + 64 s  (1024 < K <= 4096, s <= 96;
+                                       8K + 512 + 64 + 4 beyond: dy streamed);
                                        8K + 2G + 64 + 4 for 32 < K <= 1024 (dy streamed, G lanes per row)
                      no list, s <= gather_max: read p, write dx, gather dy: 8K + 4 + 64 s
                      otherwise: stream dy and p, write dx: 12K + 4
@@ -173,9 +174,11 @@ def min_traffic(K, cap, cols, supp, has_mask):
     elif small:
         masked = head == -3
     else:
-        masked = (head == -3) & (supp <= gather_max(K))
-    gath = ~listed & ~masked & (supp <= gather_max(K))
-    stream = ~listed & ~masked & ~gath
+        masked = head == -3
+    wide = masked & (supp > gather_max(K)) & (not small)   # pattern rows that stream dy: 8K + 512
+    masked = masked & ~wide
+    gath = ~listed & ~masked & ~wide & (supp <= gather_max(K))
+    stream = ~listed & ~masked & ~wide & ~gath
     n_masked_fwd = int((head == -3).sum().item()) if has_mask else 0
     fwd = R * (8.0 * K + 4 + 4 * cap) + (pat * R if (small and has_mask) else 512.0 * n_masked_fwd)
     # a pattern row of a 16-register tile streams dy: 8K + pattern + list head + supp
@@ -183,10 +186,11 @@ def min_traffic(K, cap, cols, supp, has_mask):
     masked_sectors = 0.0 if small else 64.0 * float(s[masked].sum().item())
     bwd = (float(listed.sum().item()) * (4.0 * K + 4 * cap + 4) + 64.0 * float(s[listed].sum().item())
            + float(masked.sum().item()) * masked_row + masked_sectors
+           + float(wide.sum().item()) * (8.0 * K + 512 + 64 + 4)
            + float(gath.sum().item()) * (8.0 * K + 4) + 64.0 * float(s[gath].sum().item())
            + float(stream.sum().item()) * (12.0 * K + 4))
     return {"fwd": fwd, "bwd": bwd,
-            "rows": {"listed": int(listed.sum().item()), "masked": int(masked.sum().item()),
+            "rows": {"listed": int(listed.sum().item()), "masked": int(masked.sum().item()) + int(wide.sum().item()),
                      "gather": int(gath.sum().item()), "stream": int(stream.sum().item())}}
 
 

@@ -1502,12 +1502,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
     if constexpr (MASKS) {
         // no list, but the forward left the non-zero pattern (head and s are wave-uniform here)
-        if (mask && head == kColsMask && s <= gather_max(K)) {
+        if (mask && head == kColsMask) {
             const uint2 m = reinterpret_cast<const uint2*>(mask + row * kMaskWordsPerRow)[lane];
             float a[E];
+            if (s <= gather_max(K)) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) a[e] = 0.0f;
-            bwd_row_gather_bits<E, VEC>(dy + row * K, gl, G, a, m.x, m.y, s, red);
+                for (int e = 0; e < E; ++e) a[e] = 0.0f;
+                bwd_row_gather_bits<E, VEC>(dy + row * K, gl, G, a, m.x, m.y, s, red);
+            } else {
+                // wider supports (a random 64-byte sector per element costs about as much as
+                // 350 streamed bytes: measured break-even near 96 elements at K = 4096): stream dy
+                // and select by the pattern -- same sum, same order as bwd_row, and still no p
+                load_row<E, VEC, FULL>(dy + row * K, K, gl, G, a, 0.0f);
+                double acc = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool nz = ((e < 32 ? m.x >> e : m.y >> (e - 32)) & 1u) != 0u;
+                    acc += nz ? (double)a[e] : 0.0;
+                }
+                acc = red.sum(acc);
+                const float v = (float)acc / (float)s;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool nz = ((e < 32 ? m.x >> e : m.y >> (e - 32)) & 1u) != 0u;
+                    a[e] = nz ? (a[e] - v) : 0.0f;
+                }
+            }
             if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
             return;
         }
