@@ -640,3 +640,40 @@ def test_calls_on_two_streams_do_not_interfere(dev):
     torch.cuda.synchronize()
     for i in range(2):
         assert torch.equal(out[i][0], ref[i][0]) and torch.equal(out[i][1], ref[i][1])
+
+
+@pytest.mark.parametrize("K", [8, 17, 64, 256, 700, 1500, 4096, 9000, 70000])
+def test_fuzz_rows_from_the_algorithm_model(dev, oracle_mod, K):
+    """The row generator the exact-edge algorithm was fuzzed with as a numpy model
+    (tools/edge_model.py: crowds planted at, one ulp around and just below the oracle's own
+    threshold, two-level ties, spikes, rounded rows, several scales) through the kernels: p, supp,
+    tau bit-exact, with and without the list / pattern by-products, and dx from all three
+    backward forms within 1e-6 of the row scale."""
+    from lvmhelpers import _native
+    from tools.edge_model import gen_row
+    rng = np.random.default_rng(K)
+    R = 400 if K <= 4096 else 60
+    x = np.stack([gen_row(rng, K) for _ in range(R)]).astype(np.float32)
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    xt = torch.from_numpy(x).to(dev)
+    p, supp, nnz, tau, _ = _native.sparsemax_fwd(xt, want_nnz=True, want_tau=True)
+    assert np.array_equal(supp.cpu().numpy(), s_ref)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    assert np.array_equal(tau.cpu().numpy(), tau_ref) and np.array_equal(nnz.cpu().numpy(), nnz_ref)
+    p2, supp2, _, _, _, cols, mask = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
+    assert torch.equal(p2, p) and torch.equal(supp2, supp)
+    head = cols[:, 0].cpu().numpy()
+    listed = head >= -1
+    got = np.sort(np.where(cols.cpu().numpy() >= 0, cols.cpu().numpy(), K + 1), axis=1)
+    for r in np.flatnonzero(listed)[:200]:
+        assert np.array_equal(got[r][: nnz_ref[r]], np.flatnonzero(p_ref[r] > 0))
+    assert np.all(nnz_ref[listed] <= cols.shape[1])
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    dyt = torch.from_numpy(dy).to(dev)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    scale = np.abs(dy).max(axis=1, keepdims=True)
+    dx_p = _native.sparsemax_bwd(dyt, p, supp)
+    assert np.all(np.abs(dx_p.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+    for m in (mask, None):
+        dx = _native.sparsemax_bwd_cols(dyt, cols, p, supp, m)
+        assert np.all(np.abs(dx.cpu().numpy() - dx_ref) <= 1e-6 * scale)
