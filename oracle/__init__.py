@@ -243,6 +243,43 @@ def sparsemap_bwd(dp, aset_bits, alen, invA, n):
     return out
 
 
+def sparsemap_seq_fwd(scores, trans, init_scores=None, max_iter=300):
+    """Binary sequence factor: scores [B,n] f32, trans [B,n-1] f32 (edge potentials of the 1->1
+    transitions), init_scores [B,2n] f64 or None.  Same outputs as sparsemap_fwd."""
+    scores, trans = _c32(scores), _c32(trans)
+    B, n = scores.shape
+    assert trans.shape == (B, n - 1)
+    cap, W, ld = n + 1, (n + 31) // 32, n + 2
+    init = None if init_scores is None else np.ascontiguousarray(init_scores, np.float64)
+    out = dict(
+        aset_bits=np.zeros((B, cap, W), np.uint32), p=np.zeros((B, cap), np.float32),
+        p64=np.zeros((B, cap), np.float64), alen=np.zeros(B, np.int32),
+        invA=np.zeros((B, ld, ld), np.float64), iters=np.zeros(B, np.int32),
+        status=np.zeros(B, np.int32))
+    rc = lib().oracle_sparsemap_seq_fwd(
+        _ptr(scores, _f32p), _ptr(trans, _f32p), _ptr(init, _f64p), ctypes.c_int32(max_iter),
+        ctypes.c_int64(B), ctypes.c_int32(n), _ptr(out["aset_bits"], _u32p), _ptr(out["p"], _f32p),
+        _ptr(out["p64"], _f64p), _ptr(out["alen"], _i32p), _ptr(out["invA"], _f64p),
+        _ptr(out["iters"], _i32p), _ptr(out["status"], _i32p))
+    if rc != 0:
+        raise ValueError(f"sparsemap sequence oracle: error {rc}")
+    return out
+
+
+def sparsemap_seq_bwd(dp, aset_bits, alen, invA, n):
+    """-> (dscores [B,n] f32, dtrans [B,n-1] f32)."""
+    dp = _c32(dp)
+    B = dp.shape[0]
+    ds, dt = np.zeros((B, n), np.float32), np.zeros((B, n - 1), np.float32)
+    rc = lib().oracle_sparsemap_seq_bwd(
+        _ptr(dp, _f32p), _ptr(np.ascontiguousarray(aset_bits, np.uint32), _u32p),
+        _ptr(np.ascontiguousarray(alen, np.int32), _i32p),
+        _ptr(np.ascontiguousarray(invA, np.float64), _f64p),
+        ctypes.c_int64(B), ctypes.c_int32(n), _ptr(ds, _f32p), _ptr(dt, _f32p))
+    assert rc == 0
+    return ds, dt
+
+
 def unpack_bits(aset_bits, n):
     """[..., W] u32 -> [..., n] float32 0/1."""
     a = np.asarray(aset_bits, np.uint32)

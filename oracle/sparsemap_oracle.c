@@ -9,6 +9,8 @@
  *     lvmhelpers/bernoulli.h:38-54     Evaluate;  :58-73 UpdateMarginalsFromConfiguration
  *     lvmhelpers/bernoulli.h:76-109    CountCommonValues / SameConfiguration
  *     lvmhelpers/budget.h:24-85        FactorBudget::Maximize
+ *     lvmhelpers/sequence.h:66-166, sequence_binary.h:11-67   FactorSequenceBinary (Viterbi oracle,
+ *                                      Evaluate with edge scores; sparsemap.py:47-87,130-148)
  *
  * The active-set loop itself (GenericFactor::SolveQP, InvertAfterInsertion/-Removal,
  * InitActiveSetFromScores, GetSparseSolution, DistJacobianVec) lives in the third-party package
@@ -131,6 +133,52 @@ static double maximize(const double* on, const double* off, int n, int budget, u
     return value + sum;
 }
 
+/* Linear oracle of the binary sequence factor (lvmhelpers/sequence_binary.h:11-38 on
+ * sequence.h:66-139): Viterbi over n positions with two states; node scores on[k] (state 1) /
+ * off[k] (state 0), edge score t[k-1] for the transition (1 -> 1) into position k, 0 for every
+ * other edge (start and stop included).  Ties as upstream: the first state of the scan (0) wins
+ * unless the other is strictly better.  Sums in the order of the recursion. */
+static double maximize_seq(const double* on, const double* off, const double* t, int n, uint32_t* cfg,
+                           unsigned char* from0, unsigned char* from1)
+{
+    const int W = SM_WORDS(n);
+    memset(cfg, 0, sizeof(uint32_t) * (size_t)W);
+    double v0 = off[0] + 0.0, v1 = on[0] + 0.0;
+    for (int i = 1; i < n; ++i) {
+        const double c00 = v0 + 0.0, c10 = v1 + 0.0;          /* into state 0 */
+        const int b0 = c10 > c00;
+        const double best0 = b0 ? c10 : c00;
+        const double c01 = v0 + 0.0, c11 = v1 + t[i - 1];     /* into state 1 */
+        const int b1 = c11 > c01;
+        const double best1 = b1 ? c11 : c01;
+        from0[i] = (unsigned char)b0;
+        from1[i] = (unsigned char)b1;
+        v0 = best0 + off[i];
+        v1 = best1 + on[i];
+    }
+    const double f0 = v0 + 0.0, f1 = v1 + 0.0;
+    int state = f1 > f0;
+    const double value = state ? f1 : f0;
+    for (int i = n - 1; i >= 0; --i) {
+        if (state) cfg[i >> 5] |= 1u << (i & 31);
+        if (i > 0) state = state ? from1[i] : from0[i];
+    }
+    return value;
+}
+
+/* Evaluate (bernoulli.h:38-54; sequence.h:142-166 with the binary factor's scores): eta over the
+ * on-bits in index order, and for the sequence factor t[k-1] right after position k's node score
+ * whenever bits k-1 and k are both on. */
+static double evaluate_cfg(const uint32_t* cfg, const double* eta, const double* t, int n)
+{
+    double v = 0.0;
+    for (int k = 0; k < n; ++k) {
+        v += bit_of(cfg, k) ? eta[k] : 0.0;
+        if (t) v += (k > 0 && bit_of(cfg, k - 1) && bit_of(cfg, k)) ? t[k - 1] : 0.0;
+    }
+    return v;
+}
+
 static int common_values(const uint32_t* a, const uint32_t* b, int n)
 {
     int diff = 0;
@@ -212,12 +260,18 @@ static void rebuild_inverse(double* A, int ld, const uint32_t* cfg, int m, int n
  *   invA[B,ld,ld] f64        cached inverse KKT matrix, rows/cols 0..alen meaningful (nullable)
  *   iters[B]                 loop passes used (nullable);  status[B] (nullable)
  */
-int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
-                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
-                         double* p64, int32_t* alen, double* invA_out, int32_t* iters,
-                         int32_t* status)
+static int sparsemap_fwd_impl(const float* scores, const float* trans, const double* init_scores,
+                              int32_t budget, int32_t max_iter, int64_t B, int32_t n,
+                              uint32_t* aset_bits, float* p, double* p64, int32_t* alen,
+                              double* invA_out, int32_t* iters, int32_t* status)
 {
+    /* trans != NULL: the binary sequence factor (sparsemap.py:47-87,130-148): trans[B, n-1] fp32
+     * edge potentials of the (1 -> 1) transitions, additional log-potentials that enter the
+     * configurations' scores but not the quadratic term (the oracle is called on eta - mu for the
+     * variables and on the unchanged edge potentials); InitActiveSetFromScores runs the oracle on
+     * the init scores with zero edge potentials (sparsemap.py:71-74). */
     if (n < 1 || n > SM_MAX_N) return -2;
+    if (trans && budget > 0) return -2;
     const int cap = n + 1, W = SM_WORDS(n), ld = cap + 1;
     double* eta = (double*)malloc(sizeof(double) * (size_t)n);
     double* zero = (double*)calloc((size_t)n, sizeof(double));
@@ -235,11 +289,18 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
     double* e_res = (double*)malloc(sizeof(double) * (size_t)ld);
     uint32_t* cfg = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap * W);
     uint32_t* newc = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W);
+    double* tr = (double*)calloc((size_t)n, sizeof(double));
+    unsigned char* from0 = (unsigned char*)malloc((size_t)n);
+    unsigned char* from1 = (unsigned char*)malloc((size_t)n);
 
     for (int64_t s_ = 0; s_ < B; ++s_) {
         for (int i = 0; i < n; ++i) eta[i] = (double)scores[s_ * n + i];
+        if (trans) for (int i = 0; i < n - 1; ++i) tr[i] = (double)trans[s_ * (n - 1) + i];
         int m = 0;
-        if (init_scores) /* InitActiveSetFromScores: Maximize(init) */
+        if (trans) {
+            if (init_scores) maximize_seq(init_scores + s_ * 2 * n, init_scores + s_ * 2 * n + n, zero, n, cfg, from0, from1);
+            else maximize_seq(eta, zero, tr, n, cfg, from0, from1);
+        } else if (init_scores) /* InitActiveSetFromScores: Maximize(init) */
             maximize(init_scores + s_ * 2 * n, init_scores + s_ * 2 * n + n, n, budget, cfg, e_tmp, idx_tmp);
         else /* SolveQP with empty active set: Maximize(eta) */
             maximize(eta, zero, n, budget, cfg, e_tmp, idx_tmp);
@@ -254,11 +315,8 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
             if (rejudges > 0 && it - last_rejudge > SM_KKT_PATIENCE) { st = SM_STALLED; break; } /* C7 */
             if (changed) {
                 bvec[0] = 1.0;
-                for (int i = 0; i < m; ++i) { /* Evaluate under eta = [x; 0] */
-                    double v = 0.0;
-                    for (int k = 0; k < n; ++k) v += bit_of(cfg + i * W, k) ? eta[k] : 0.0;
-                    bvec[i + 1] = v;
-                }
+                for (int i = 0; i < m; ++i) /* Evaluate under eta = [x; 0] (and the edge potentials) */
+                    bvec[i + 1] = evaluate_cfg(cfg + i * W, eta, trans ? tr : NULL, n);
                 for (int c = 0; c <= m; ++c) {
                     double acc = 0.0;
                     for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
@@ -273,7 +331,8 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                     for (int k = 0; k < n; ++k)
                         if (bit_of(cfg + i * W, k)) mu_on[k] += z[i]; else mu_off[k] += z[i];
                 for (int k = 0; k < n; ++k) { mu_on[k] = eta[k] - mu_on[k]; mu_off[k] = 0.0 - mu_off[k]; }
-                double value = maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
+                double value = trans ? maximize_seq(mu_on, mu_off, tr, n, newc, from0, from1)
+                                     : maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
                 if (value <= tau + 1e-9) {
                     /* C7: accept only an accurate solution of the KKT system */
                     const double rho0 = kkt_residual(z, tau, bvec, cfg, m, n, r);
@@ -322,7 +381,7 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 int dup = 0;
                 for (int i = 0; i < m && !dup; ++i) dup = (memcmp(cfg + i * W, newc, sizeof(uint32_t) * W) == 0);
                 if (dup) { st = SM_DUPLICATE; break; }
-                if (m >= cap) { st = SM_SINGULAR; break; } /* n+1 affinely independent vertices at most */
+                if (m >= cap && !trans) { st = SM_SINGULAR; break; } /* n+1 affinely independent vertices at most (C8 swaps) */
                 z[m] = 0.0;
                 for (int i = 0; i <= m; ++i) dist[i] = z[i];
                 /* InvertAfterInsertion */
@@ -335,7 +394,65 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
                 }
                 double s = (double)n;
                 for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
-                if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
+                double w_new = 0.0;   /* weight the new vertex starts with */
+                if (s <= 1e-9 && s >= -1e-9) {
+                    if (!trans) { st = SM_SINGULAR; break; }
+                    /* C8 (sequence factor only): the new vertex is an affine combination of the
+                     * active ones in variable space, y_new = sum_i c_i y_i with c = d[1..m] (d
+                     * solves the KKT system for r).  Its score is higher than the same combination
+                     * of theirs (that is what value > tau says), so weight moves onto it along
+                     * p_i -= theta c_i, which changes neither the marginals nor sum p, until the
+                     * first active vertex reaches zero (first index on ties); that vertex leaves
+                     * and the new one enters with weight theta. */
+                    int leaving = -1;
+                    double theta = 0.0;
+                    for (int i = 0; i < m; ++i) {
+                        if (!(d[i + 1] > 0)) continue;
+                        const double tq = dist[i] / d[i + 1];
+                        if (leaving < 0 || tq < theta) { theta = tq; leaving = i; }
+                    }
+                    if (leaving < 0) { st = SM_SINGULAR; break; }
+                    for (int i = 0; i < m; ++i) { const double tq = theta * d[i + 1]; dist[i] = dist[i] - tq; z[i] = dist[i]; }
+                    { /* InvertAfterRemoval(leaving) and erase, as in the blocking branch */
+                        int ri = leaving + 1;
+                        double invs_r = A[ri * ld + ri];
+                        double sdiv = 1.0 / invs_r;
+                        int kk = 0;
+                        for (int i = 0; i <= m; ++i) { if (i == ri) continue; d[kk++] = -sdiv * A[ri * ld + i]; }
+                        kk = 0;
+                        for (int i = 0; i <= m; ++i) {
+                            if (i == ri) continue;
+                            int l = 0;
+                            for (int j = 0; j <= m; ++j) {
+                                if (j == ri) continue;
+                                A2[kk * ld + l] = A[i * ld + j] - invs_r * d[kk] * d[l];
+                                ++l;
+                            }
+                            ++kk;
+                        }
+                        { double* t_ = A; A = A2; A2 = t_; }
+                        for (int i = leaving; i < m - 1; ++i) {
+                            memcpy(cfg + i * W, cfg + (i + 1) * W, sizeof(uint32_t) * W);
+                            z[i] = z[i + 1];
+                            dist[i] = dist[i + 1];
+                        }
+                        --m;
+                    }
+                    /* the insertion again, on the reduced set */
+                    r[0] = 1.0;
+                    for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
+                    for (int j = 0; j <= m; ++j) {
+                        double acc = 0.0;
+                        for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; acc += A[i * ld + j] * r[i]; }
+                        d[j] = acc;
+                    }
+                    s = (double)n;
+                    for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
+                    if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
+                    w_new = theta;
+                }
+                z[m] = w_new;
+                dist[m] = w_new;
                 double invs = 1.0 / s;
                 for (int i = 0; i <= m; ++i) {
                     for (int j = 0; j <= m; ++j) A2[i * ld + j] = A[i * ld + j] + invs * d[i] * d[j];
@@ -417,7 +534,29 @@ int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t
     }
     free(eta); free(zero); free(mu_on); free(mu_off); free(e_tmp); free(idx_tmp); free(A); free(A2);
     free(z); free(dist); free(bvec); free(r); free(d); free(e_res); free(cfg); free(newc);
+    free(tr); free(from0); free(from1);
     return 0;
+}
+
+int oracle_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
+                         int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                         double* p64, int32_t* alen, double* invA_out, int32_t* iters,
+                         int32_t* status)
+{
+    return sparsemap_fwd_impl(scores, NULL, init_scores, budget, max_iter, B, n, aset_bits, p, p64, alen,
+                              invA_out, iters, status);
+}
+
+/* Binary sequence factor (sequence_smap, lvmhelpers/sparsemap.py:47-87,130-148,159-160):
+ * scores[B,n], trans[B,n-1] fp32; everything else as oracle_sparsemap_fwd. */
+int oracle_sparsemap_seq_fwd(const float* scores, const float* trans, const double* init_scores,
+                             int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                             double* p64, int32_t* alen, double* invA_out, int32_t* iters,
+                             int32_t* status)
+{
+    if (!trans || n < 2) return -2;
+    return sparsemap_fwd_impl(scores, trans, init_scores, 0, max_iter, B, n, aset_bits, p, p64, alen,
+                              invA_out, iters, status);
 }
 
 /* dp[B,cap] fp32 (entries >= alen ignored) -> dscores[B,n] fp32.
@@ -441,6 +580,35 @@ int oracle_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32
             for (int i = 0; i < m; ++i)
                 if (bit_of(aset_bits + (s_ * cap + i) * W, k)) acc += tmp[i];
             dscores[s_ * n + k] = (float)acc;
+        }
+    }
+    free(tmp);
+    return 0;
+}
+
+/* SequenceSparseMAP.jv (sparsemap.py:79-87): as above, plus d_eta_v = N tmp over the n-1 edge
+ * potentials, N_i[k] = 1 iff configuration i has bits k and k+1 on (sequence_binary.h:56-67). */
+int oracle_sparsemap_seq_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
+                             const double* invA, int64_t B, int32_t n, float* dscores, float* dtrans)
+{
+    const int cap = n + 1, W = SM_WORDS(n), ld = cap + 1;
+    if (oracle_sparsemap_bwd(dp, aset_bits, alen, invA, B, n, dscores)) return -1;
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)cap);
+    for (int64_t s_ = 0; s_ < B; ++s_) {
+        const int m = alen[s_];
+        const double* A = invA + s_ * (int64_t)ld * ld;
+        for (int i = 0; i < m; ++i) {
+            double acc = 0.0;
+            for (int j = 0; j < m; ++j) acc += A[(i + 1) * ld + (j + 1)] * (double)dp[s_ * cap + j];
+            tmp[i] = acc;
+        }
+        for (int k = 0; k + 1 < n; ++k) {
+            double acc = 0.0;
+            for (int i = 0; i < m; ++i) {
+                const uint32_t* c = aset_bits + (s_ * cap + i) * W;
+                if (bit_of(c, k) && bit_of(c, k + 1)) acc += tmp[i];
+            }
+            dtrans[s_ * (n - 1) + k] = (float)acc;
         }
     }
     free(tmp);
