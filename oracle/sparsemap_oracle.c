@@ -450,6 +450,9 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                     for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
                     if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
                     w_new = theta;
+                } else if (m >= cap) { /* a full set that rounding calls independent: no room */
+                    st = SM_SINGULAR;
+                    break;
                 }
                 z[m] = w_new;
                 dist[m] = w_new;
