@@ -195,6 +195,25 @@ int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t 
 int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
                         const double* inv_a, int64_t B, int32_t n, float* dscores, void* stream);
 
+/* The binary sequence factor on the same solver (sequence_smap, lvmhelpers/sparsemap.py:47-87,
+ * 130-148,159-160; FactorSequenceBinary of lvmhelpers/sequence_binary.h:11-67 on sequence.h:66-166):
+ * n positions with states {0,1}; trans [B, n-1] fp32 are the additional log-potentials
+ * (set_additional_log_potentials, sparsemap.py:62-63), the score of the (1 -> 1) transition into
+ * position k+1.  Linear oracle = Viterbi (first state wins ties), Evaluate adds the edge scores,
+ * InitActiveSetFromScores runs on init_scores with zero edge potentials (sparsemap.py:67-69).  Edge
+ * potentials are not functions of the variable marginals, so active sets can be affinely dependent
+ * in variable space: a singular insertion swaps a vertex out (oracle/sparsemap_oracle.c C8) where
+ * the bit-vector factors report status 2.  2 <= n <= SMLVM_SPARSEMAP_MAX_BITS; outputs, workspace
+ * and status codes as smlvm_sparsemap_fwd.  Backward (SequenceSparseMAP.jv, sparsemap.py:79-87):
+ * dp [B, cap] -> dscores [B, n] and dtrans [B, n-1]. */
+int smlvm_sparsemap_seq_fwd(const float* scores, const float* trans, const double* init_scores,
+                            int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits, float* p,
+                            int32_t* alen, double* inv_a, int32_t* iters, int32_t* status,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int smlvm_sparsemap_seq_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
+                            const double* inv_a, int64_t B, int32_t n, float* dscores,
+                            float* dtrans, void* stream);
+
 /* Expand compacted (sample, slot) pairs into 0/1 float rows: out[j, :] = bits of
  * aset_bits[rows[j], cols[j], :]  (the `samplei[distri > 0]` gather + torch.cat of
  * lvmhelpers/structmarg.py:189,198).  out [N, n] fp32. */

@@ -370,6 +370,96 @@ struct Sm {
         evalsum = acc[2];
         wsync();
     }
+
+    // Linear oracle of the binary sequence factor (lvmhelpers/sequence_binary.h:11-38 on
+    // sequence.h:66-139; oracle/sparsemap_oracle.c maximize_seq): Viterbi over n positions with two
+    // states, node scores on[] / off[], edge score trs[k] = t[k-1] for the (1 -> 1) transition into
+    // position k (use_trans = false: zero edge potentials, InitActiveSetFromScores).  The recursion
+    // is serial by nature; every lane walks it on LDS broadcasts and gets the same bits.  Returns
+    // the value and Evaluate(newc) (sequence.h:142-166): node and edge scores interleaved in
+    // position order, under eta and the TRUE edge potentials.
+    __device__ __forceinline__ void maximize_seq(const double (&on)[NK], const double (&off)[NK],
+                                                 const double (&eta)[NK], const double (&trs)[NK],
+                                                 bool use_trans, double& value, double& evalsum) const
+    {
+        double* a0 = c0();
+        double* a1 = c1();
+        double* a2 = c2();
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = lane + 64 * q;
+            const bool valid = k < n;
+            a0[k] = valid ? on[q] : 0.0;
+            a1[k] = valid ? off[q] : 0.0;
+            a2[k] = (valid && use_trans) ? trs[q] : 0.0;
+        }
+        wsync();
+        // position 0 as a step from v0 = v1 = 0 with trs[0] = 0: 0.0 + x == x + 0.0 bit for bit
+        double v0 = 0.0, v1 = 0.0;
+        unsigned long long f0[NK], f1[NK];
+#pragma unroll
+        for (int q = 0; q < NK; ++q) { f0[q] = 0ull; f1[q] = 0ull; }
+        for (int i0 = 0; i0 < n8; i0 += 8) {
+            double o[8], f[8], t[8];
+            ld8(a0 + i0, o);
+            ld8(a1 + i0, f);
+            ld8(a2 + i0, t);
+            unsigned long long m0 = 0ull, m1 = 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double c00 = v0 + 0.0, c10 = v1 + 0.0;      // into state 0
+                const bool b0 = (__ballot(c10 > c00) & 1ull) != 0ull;   // lane 0 is always active
+                const double best0 = b0 ? c10 : c00;
+                const double c01 = v0 + 0.0, c11 = v1 + t[u];      // into state 1
+                const bool b1 = (__ballot(c11 > c01) & 1ull) != 0ull;
+                const double best1 = b1 ? c11 : c01;
+                const double nv0 = best0 + f[u], nv1 = best1 + o[u];
+                const bool live = i0 + u < n;
+                v0 = live ? nv0 : v0;
+                v1 = live ? nv1 : v1;
+                m0 |= (unsigned long long)b0 << u;
+                m1 |= (unsigned long long)b1 << u;
+            }
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+                if ((i0 >> 6) == q) { f0[q] |= m0 << (i0 & 63); f1[q] |= m1 << (i0 & 63); }
+        }
+        const double e0 = v0 + 0.0, e1 = v1 + 0.0;
+        bool state = (__ballot(e1 > e0) & 1ull) != 0ull;
+        value = state ? e1 : e0;
+        unsigned long long bits[NK];
+#pragma unroll
+        for (int q = 0; q < NK; ++q) bits[q] = 0ull;
+#pragma unroll
+        for (int q = NK - 1; q >= 0; --q) {
+            const int top = (n - 64 * q) < 64 ? (n - 64 * q) : 64;   // positions of this word
+            for (int b = top - 1; b >= 0; --b) {
+                if (state) bits[q] |= 1ull << b;
+                if (b + 64 * q > 0) state = ((state ? f1[q] : f0[q]) >> b) & 1ull;
+            }
+        }
+        wsync();   // the recursion's reads of a2 are done before it is reused below
+        // Evaluate: ev[2k] = node score of position k, ev[2k+1] = edge score into position k
+        double* ev = a2;   // c2 and e are contiguous: 2 NV doubles
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = lane + 64 * q;
+            const bool valid = k < n;
+            const bool bit = valid && ((bits[q] >> lane) & 1ull);
+            bool prev;
+            if (lane > 0) prev = (bits[q] >> (lane - 1)) & 1ull;
+            else prev = q > 0 ? ((bits[q > 0 ? q - 1 : 0] >> 63) & 1ull) : false;
+            ev[2 * k] = bit ? eta[q] : 0.0;
+            ev[2 * k + 1] = (bit && prev) ? trs[q] : 0.0;
+            put_bits(q, bits[q]);
+        }
+        wsync();
+        const double* const arr[1] = {ev};
+        double acc[1];
+        serial_sums<1>(arr, round8(2 * n), acc);
+        evalsum = acc[0];
+        wsync();
+    }
 };
 
 // ---- C7 of oracle/sparsemap_oracle.c: a convergence is only accepted on an accurate KKT solution
@@ -498,9 +588,13 @@ __device__ __forceinline__ void rebuild_inverse(double* A, const uint32_t* cfg, 
     }
 }
 
-template <int LD, int WT, int NK>
+// SEQ: the binary sequence factor (sequence_smap, lvmhelpers/sparsemap.py:47-87,130-148): trans
+// [B, n-1] fp32 edge potentials of the (1 -> 1) transitions; Viterbi oracle, edge scores in
+// Evaluate, and choice C8 of oracle/sparsemap_oracle.c (vertex swap on a singular insertion).
+template <int LD, int WT, int NK, bool SEQ>
 __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
-    const float* __restrict__ scores, const double* __restrict__ init_scores, int budget,
+    const float* __restrict__ scores, const float* __restrict__ trans,
+    const double* __restrict__ init_scores, int budget,
     int max_iter, int64_t B, int n, uint32_t* __restrict__ aset_bits, float* __restrict__ p_out,
     int32_t* __restrict__ alen, double* __restrict__ a_out, int32_t* __restrict__ iters,
     int32_t* __restrict__ status, int resume, int32_t* __restrict__ ws_state,
@@ -539,10 +633,15 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         for (int i = lane; i < (int)(L::total / 16); i += 64) all[i] = zero2;
     }
     double eta[NK], on[NK], off[NK];
+    double trs[NK];   // SEQ: trs[q] = t[k-1], the edge potential into position k = lane + 64 q
 #pragma unroll
     for (int q = 0; q < NK; ++q) {
         const int k = lane + 64 * q;
         eta[q] = 0.0; on[q] = 0.0; off[q] = 0.0;
+        trs[q] = 0.0;
+        if constexpr (SEQ) {
+            if (k >= 1 && k < n) trs[q] = (double)trans[s * (n - 1) + k - 1];
+        }
         if (k < n) {
             const double x = (double)scores[s * n + k];
             eta[q] = x;
@@ -561,7 +660,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     double tau = 0.0;
     if (!resume) {
         double value, evalsum;
-        S.maximize(on, off, eta, budget, value, evalsum);
+        if constexpr (SEQ) S.maximize_seq(on, off, eta, trs, init_scores == nullptr, value, evalsum);
+        else S.maximize(on, off, eta, budget, value, evalsum);
         if (lane < WT) cfg[lane] = newc[lane];
         if (lane == 0) {
             dist[0] = 1.0;
@@ -618,6 +718,127 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         tau = accumulate ? uni(tau + t0) : uni(t0);
         wsync();
     };
+    // InvertAfterRemoval(idx) and erase entry idx of the active set (m decreases by one)
+    auto remove_entry = [&](int idx) {
+        // InvertAfterRemoval
+        const int ri = idx + 1;
+        wsync();
+        const double invs = uni(A[ri * LD + ri]);
+        const double sdiv = uni(1.0 / invs);
+        for (int i = lane; i <= m; i += 64)
+            if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * LD + i];
+        wsync();
+        // in place with compaction: targets never pass the sources in row-major order.
+        // Rows go in batches of 4: all reads of a batch are issued before its writes (one
+        // wave: LDS executes in order), and a batch only writes rows it has already read.
+        for (int i0 = 0; i0 <= m; i0 += 4) {
+#pragma unroll
+            for (int q = 0; q * 64 < LD; ++q) {
+                const int j = lane + 64 * q;
+                const bool okj = (j <= m) && (j != ri);
+                const int l = j - (j > ri ? 1 : 0);
+                double v[4], dk[4];
+                const double dl = okj ? d[l] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u;
+                    const int ic = i <= m ? i : m;
+                    const int kk = ic - (ic > ri ? 1 : 0);
+                    v[u] = okj ? A[ic * LD + j] : 0.0;
+                    dk[u] = d[kk];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u;
+                    if (okj && i <= m && i != ri) {
+                        const int kk = i - (i > ri ? 1 : 0);
+                        A[kk * LD + l] = v[u] - invs * dk[u] * dl;
+                    }
+                }
+            }
+        }
+        // erase entry `idx` from cfg / z / dist / bsc (chunks ascending: read, then write)
+        for (int i0 = idx; i0 < m; i0 += 64) {
+            const int i = i0 + lane;
+            const bool ok = i < m - 1;
+            const bool last = i == m - 1;   // vacated slot: back to zero (padding invariant)
+            double zv = 0.0, dv = 0.0, bv = 0.0;
+            uint32_t cw[WT];
+#pragma unroll
+            for (int w = 0; w < WT; ++w) cw[w] = 0u;
+            if (ok) {
+                zv = z[i + 1]; dv = dist[i + 1]; bv = bsc[i + 2];
+#pragma unroll
+                for (int w = 0; w < WT; ++w) cw[w] = cfg[(i + 1) * WT + w];
+            }
+            wsync();
+            if (ok || last) {
+                z[i] = zv; dist[i] = dv; bsc[i + 1] = bv;
+#pragma unroll
+                for (int w = 0; w < WT; ++w) cfg[i * WT + w] = cw[w];
+            }
+            wsync();
+        }
+        --m;
+    };
+    // r = [1; CountCommonValues(cfg_i, new)]; true if the new configuration is already active
+    auto common_with_new = [&]() -> bool {
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q * 64 < L::NA; ++q) {
+            const int i = lane + 64 * q;   // KKT index: 0 -> 1.0, i >= 1 -> configuration i-1
+            if (i < L::NA) {
+                double ri = 0.0;
+                if (i == 0) ri = 1.0;
+                else if (i <= m) {
+                    int diff = 0;
+#pragma unroll
+                    for (int w = 0; w < WT; ++w) diff += __popc(cfg[(i - 1) * WT + w] ^ newc[w]);
+                    dup = dup || (diff == 0);
+                    ri = (double)(n - diff);
+                }
+                r[i] = ri;
+            }
+        }
+        return __any(dup) != 0;
+    };
+    // d = invA r (zero beyond m), prod = r .* d; returns s = n - sum_j r_j d_j (serial)
+    auto insertion_direction = [&]() -> double {
+        wsync();
+        const int cnt8 = round8(m + 1);
+#pragma unroll
+        for (int q = 0; q * 64 < L::NA; ++q) {
+            const int j = lane + 64 * q;
+            if (q * 64 <= cnt8 && j < L::NA) {
+                const int jj = j < LD ? j : LD - 1;
+                const double acc = matvec_col<LD>(A + jj, r, cnt8);
+                const double dj = (j <= m) ? acc : 0.0;
+                d[j] = dj;
+                prod[j] = r[j] * dj;   // r is 0 beyond m
+            }
+        }
+        wsync();
+        SM_T(4);
+        double acc = (double)n;
+        double a[8], b[8];
+        ld8(prod, a);
+        int k0 = 0;
+        for (;;) {
+            int kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
+            ld8(prod + kn, b);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc -= a[u];
+            k0 += 8;
+            if (k0 >= cnt8) break;
+            kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
+            ld8(prod + kn, a);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc -= b[u];
+            k0 += 8;
+            if (k0 >= cnt8) break;
+        }
+        return acc;
+    };
     for (; it < max_iter; ++it) {
         bool same = true;
         if (rejudges > 0 && it - last_rejudge > kKktPatience) { st = SM_STALLED; break; }   // C7
@@ -638,7 +859,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             }
             SM_T(1);
             double value, evalsum;
-            S.maximize(on, off, eta, budget, value, evalsum);
+            if constexpr (SEQ) S.maximize_seq(on, off, eta, trs, true, value, evalsum);
+            else S.maximize(on, off, eta, budget, value, evalsum);
             SM_T(2);
             if (uni(value <= tau + 1e-9)) {
                 // C7: accept only an accurate solution of the KKT system
@@ -677,26 +899,11 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 break;
             }
             // SameConfiguration against every active entry + r = [1; CountCommonValues(cfg_i, new)]
-            bool dup = false;
-#pragma unroll
-            for (int q = 0; q * 64 < L::NA; ++q) {
-                const int i = lane + 64 * q;   // KKT index: 0 -> 1.0, i >= 1 -> configuration i-1
-                if (i < L::NA) {
-                    double ri = 0.0;
-                    if (i == 0) ri = 1.0;
-                    else if (i <= m) {
-                        int diff = 0;
-#pragma unroll
-                        for (int w = 0; w < WT; ++w) diff += __popc(cfg[(i - 1) * WT + w] ^ newc[w]);
-                        dup = dup || (diff == 0);
-                        ri = (double)(n - diff);
-                    }
-                    r[i] = ri;
-                }
+            if (common_with_new()) { st = SM_DUPLICATE; break; }
+            if constexpr (!SEQ) {
+                if (m >= cap) { st = SM_SINGULAR; break; }
+                if (m + 2 > LD) { overflow = true; break; }   // next tier redoes this pass
             }
-            if (__any(dup)) { st = SM_DUPLICATE; break; }
-            if (m >= cap) { st = SM_SINGULAR; break; }
-            if (m + 2 > LD) { overflow = true; break; }   // next tier redoes this pass
             // z.push_back(0); distribution = z
             for (int i = lane; i <= m; i += 64) {
                 const double zi = (i < m) ? z[i] : 0.0;
@@ -705,45 +912,55 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             }
             wsync();
             SM_T(3);
-            // InvertAfterInsertion: d = invA r
+            // InvertAfterInsertion: d = invA r, s = n - r.d
+            double sden = insertion_direction();
+            double w_new = 0.0;   // weight the new vertex starts with
+            if (uni(sden <= 1e-9 && sden >= -1e-9)) {
+                if constexpr (!SEQ) { st = SM_SINGULAR; break; }
+                // C8 (sequence factor only): the new vertex is an affine combination of the active
+                // ones in variable space, y_new = sum_i c_i y_i with c = d[1..m].  Its score is
+                // higher than the same combination of theirs, so weight moves onto it along
+                // p_i -= theta c_i (marginals and sum p unchanged) until the first active vertex
+                // reaches zero (first index on ties); that vertex leaves, the new one enters with
+                // weight theta.
+                double best = INFINITY;
+                int best_i = 0x7fffffff;
+                for (int i = lane; i < m; i += 64) {
+                    const double di = d[i + 1];
+                    if (!(di > 0)) continue;
+                    const double tq = dist[i] / di;
+                    if (best_i == 0x7fffffff || tq < best) { best = tq; best_i = i; }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    const double ob = bcast_f64(best, (lane ^ o));
+                    const int oi = __shfl(best_i, lane ^ o);
+                    if (oi != 0x7fffffff &&
+                        (best_i == 0x7fffffff || ob < best || (ob == best && oi < best_i))) {
+                        best = ob;
+                        best_i = oi;
+                    }
+                }
+                const int leaving = uni(best_i);
+                if (leaving == 0x7fffffff) { st = SM_SINGULAR; break; }
+                const double theta = uni(best);
+                for (int i = lane; i < m; i += 64) {
+                    const double tq = theta * d[i + 1];
+                    const double v = dist[i] - tq;
+                    dist[i] = v;
+                    z[i] = v;
+                }
+                remove_entry(leaving);
+                // the insertion again, on the reduced set
+                common_with_new();
+                sden = insertion_direction();
+                if (uni(sden <= 1e-9 && sden >= -1e-9)) { st = SM_SINGULAR; break; }
+                w_new = theta;
+            } else if constexpr (SEQ) {
+                if (m >= cap) { st = SM_SINGULAR; break; }   // a full set that rounding calls independent
+                if (m + 2 > LD) { overflow = true; break; }  // next tier redoes this pass
+            }
             const int cnt8 = round8(m + 1);
-#pragma unroll
-            for (int q = 0; q * 64 < L::NA; ++q) {
-                const int j = lane + 64 * q;
-                if (q * 64 <= cnt8 && j < L::NA) {
-                    const int jj = j < LD ? j : LD - 1;
-                    const double acc = matvec_col<LD>(A + jj, r, cnt8);
-                    const double dj = (j <= m) ? acc : 0.0;
-                    d[j] = dj;
-                    prod[j] = r[j] * dj;   // r is 0 beyond m
-                }
-            }
-            wsync();
-            SM_T(4);
-            double sden;
-            {
-                // s = n - sum_j r_j d_j, serial
-                double acc = (double)n;
-                double a[8], b[8];
-                ld8(prod, a);
-                int k0 = 0;
-                for (;;) {
-                    int kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
-                    ld8(prod + kn, b);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc -= a[u];
-                    k0 += 8;
-                    if (k0 >= cnt8) break;
-                    kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
-                    ld8(prod + kn, a);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc -= b[u];
-                    k0 += 8;
-                    if (k0 >= cnt8) break;
-                }
-                sden = acc;
-            }
-            if (uni(sden <= 1e-9 && sden >= -1e-9)) { st = SM_SINGULAR; break; }
             const double invs = uni(1.0 / sden);
             // t1 = invs * d (zero beyond m)
 #pragma unroll
@@ -781,6 +998,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             if (lane == 0) {
                 A[(m + 1) * LD + (m + 1)] = invs;
                 bsc[m + 1] = evalsum;
+                if constexpr (SEQ) { z[m] = w_new; dist[m] = w_new; }
             }
             if (lane < WT) cfg[m * WT + lane] = newc[lane];
             ++m;
@@ -826,66 +1044,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                         dist[i] = v;
                     }
                 }
-                // InvertAfterRemoval
-                const int ri = blocking + 1;
-                wsync();
-                const double invs = uni(A[ri * LD + ri]);
-                const double sdiv = uni(1.0 / invs);
-                for (int i = lane; i <= m; i += 64)
-                    if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * LD + i];
-                wsync();
-                // in place with compaction: targets never pass the sources in row-major order.
-                // Rows go in batches of 4: all reads of a batch are issued before its writes (one
-                // wave: LDS executes in order), and a batch only writes rows it has already read.
-                for (int i0 = 0; i0 <= m; i0 += 4) {
-#pragma unroll
-                    for (int q = 0; q * 64 < LD; ++q) {
-                        const int j = lane + 64 * q;
-                        const bool okj = (j <= m) && (j != ri);
-                        const int l = j - (j > ri ? 1 : 0);
-                        double v[4], dk[4];
-                        const double dl = okj ? d[l] : 0.0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = i0 + u;
-                            const int ic = i <= m ? i : m;
-                            const int kk = ic - (ic > ri ? 1 : 0);
-                            v[u] = okj ? A[ic * LD + j] : 0.0;
-                            dk[u] = d[kk];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = i0 + u;
-                            if (okj && i <= m && i != ri) {
-                                const int kk = i - (i > ri ? 1 : 0);
-                                A[kk * LD + l] = v[u] - invs * dk[u] * dl;
-                            }
-                        }
-                    }
-                }
-                // erase entry `blocking` from cfg / z / dist / bsc (chunks ascending: read, then write)
-                for (int i0 = blocking; i0 < m; i0 += 64) {
-                    const int i = i0 + lane;
-                    const bool ok = i < m - 1;
-                    const bool last = i == m - 1;   // vacated slot: back to zero (padding invariant)
-                    double zv = 0.0, dv = 0.0, bv = 0.0;
-                    uint32_t cw[WT];
-#pragma unroll
-                    for (int w = 0; w < WT; ++w) cw[w] = 0u;
-                    if (ok) {
-                        zv = z[i + 1]; dv = dist[i + 1]; bv = bsc[i + 2];
-#pragma unroll
-                        for (int w = 0; w < WT; ++w) cw[w] = cfg[(i + 1) * WT + w];
-                    }
-                    wsync();
-                    if (ok || last) {
-                        z[i] = zv; dist[i] = dv; bsc[i + 1] = bv;
-#pragma unroll
-                        for (int w = 0; w < WT; ++w) cfg[i * WT + w] = cw[w];
-                    }
-                    wsync();
-                }
-                --m;
+                remove_entry(blocking);
                 changed = true;
                 judged = false;
                 wsync();
@@ -930,7 +1089,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
 __global__ __launch_bounds__(64) void sparsemap_bwd_kernel(
     const float* __restrict__ dp, const uint32_t* __restrict__ aset_bits,
     const int32_t* __restrict__ alen, const double* __restrict__ inv_a, int64_t B, int n,
-    float* __restrict__ dscores)
+    float* __restrict__ dscores, float* __restrict__ dtrans)
 {
     extern __shared__ __align__(16) char sm[];
     double* tmp = (double*)sm;                         // [cap]
@@ -955,6 +1114,19 @@ __global__ __launch_bounds__(64) void sparsemap_bwd_kernel(
         for (int i = 0; i < m; ++i)
             if ((cfg[i * W + (k >> 5)] >> (k & 31)) & 1u) acc += tmp[i];
         dscores[s * n + k] = (float)acc;
+    }
+    // SequenceSparseMAP.jv (sparsemap.py:79-87): d_eta_v[k] = sum over the configurations that
+    // have bits k and k+1 on (sequence_binary.h:56-67)
+    if (dtrans) {
+        for (int k = lane; k + 1 < n; k += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < m; ++i) {
+                const uint32_t b0 = (cfg[i * W + (k >> 5)] >> (k & 31)) & 1u;
+                const uint32_t b1 = (cfg[i * W + ((k + 1) >> 5)] >> ((k + 1) & 31)) & 1u;
+                if (b0 & b1) acc += tmp[i];
+            }
+            dtrans[s * (n - 1) + k] = (float)acc;
+        }
     }
 }
 
@@ -984,12 +1156,12 @@ static int device_cus()
 }
 
 struct SmArgs {
-    const float* scores; const double* init_scores; int32_t budget, max_iter; int64_t B; int32_t n;
+    const float* scores; const float* trans; const double* init_scores; int32_t budget, max_iter; int64_t B; int32_t n;
     uint32_t* aset_bits; float* p; int32_t* alen; double* a_out; int32_t* iters; int32_t* status;
     int32_t* ws_state; int32_t* ws_it; double* ws_tau; double* ws_vec; hipStream_t stream;
 };
 
-template <int LD, int WT, int NK>
+template <int LD, int WT, int NK, bool SEQ>
 static int launch_sm_fwd(const SmArgs& a, int resume)
 {
     using L = SmLayout<LD, WT, NK>;
@@ -998,7 +1170,7 @@ static int launch_sm_fwd(const SmArgs& a, int resume)
     static std::atomic<bool> configured[kMaxDevices];
     const int dev = current_device();
     if (L::total > 48 * 1024 && !configured[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel<LD, WT, NK>,
+        if (hipFuncSetAttribute((const void*)sparsemap_fwd_kernel<LD, WT, NK, SEQ>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)L::total) != hipSuccess) {
             g_last_hip_error = (int)hipGetLastError();
@@ -1006,8 +1178,8 @@ static int launch_sm_fwd(const SmArgs& a, int resume)
         }
         configured[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK>), dim3((unsigned)a.B), dim3(64), L::total,
-                       a.stream, a.scores, a.init_scores, a.budget, a.max_iter, a.B, a.n,
+    hipLaunchKernelGGL((sparsemap_fwd_kernel<LD, WT, NK, SEQ>), dim3((unsigned)a.B), dim3(64), L::total,
+                       a.stream, a.scores, a.trans, a.init_scores, a.budget, a.max_iter, a.B, a.n,
                        a.aset_bits, a.p, a.alen, a.a_out, a.iters, a.status, resume, a.ws_state,
                        a.ws_it, a.ws_tau, a.ws_vec);
     return check_launch();
@@ -1035,24 +1207,18 @@ extern "C" size_t smlvm_sparsemap_fwd_workspace_bytes(int64_t B, int32_t n, int3
     return bytes;
 }
 
-extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
-                                   int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits,
-                                   float* p, int32_t* alen, double* inv_a, int32_t* iters,
-                                   int32_t* status, void* workspace, size_t workspace_bytes,
-                                   void* stream)
+// Shared dispatcher: SEQ = false the Bernoulli / budget factors, true the binary sequence factor.
+template <bool SEQ>
+static int run_sm_fwd(SmArgs a, void* workspace, size_t workspace_bytes)
 {
-    if (B < 0 || n < 1 || max_iter < 0 || budget < 0) return SMLVM_ERR_INVALID;
-    if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
-    if (B == 0) return SMLVM_OK;
-    if (!scores || !aset_bits || !p || !alen) return SMLVM_ERR_INVALID;
-    SmArgs a{scores, init_scores, budget, max_iter, B, n, aset_bits, p, alen, inv_a, iters, status,
-             nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
-    if (n <= 8) return launch_sm_fwd<10, 1, 1>(a, 0);
-    if (n <= 16) return launch_sm_fwd<18, 1, 1>(a, 0);
-    if (n <= 32) return launch_sm_fwd<34, 1, 1>(a, 0);
-    if (n <= 64) return launch_sm_fwd<66, 2, 1>(a, 0);
+    const int64_t B = a.B;
+    const int n = a.n;
+    if (n <= 8) return launch_sm_fwd<10, 1, 1, SEQ>(a, 0);
+    if (n <= 16) return launch_sm_fwd<18, 1, 1, SEQ>(a, 0);
+    if (n <= 32) return launch_sm_fwd<34, 1, 1, SEQ>(a, 0);
+    if (n <= 64) return launch_sm_fwd<66, 2, 1, SEQ>(a, 0);
     // tiers
-    const size_t need = smlvm_sparsemap_fwd_workspace_bytes(B, n, inv_a != nullptr);
+    const size_t need = smlvm_sparsemap_fwd_workspace_bytes(B, n, a.a_out != nullptr);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7u))
         return SMLVM_ERR_WORKSPACE;
     const size_t ldo = (size_t)n + 2;
@@ -1064,21 +1230,51 @@ extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_score
     w += align256(sizeof(double) * (size_t)B);
     a.ws_vec = reinterpret_cast<double*>(w);
     w += align256(sizeof(double) * 3 * ldo * (size_t)B);
-    if (!inv_a) a.a_out = reinterpret_cast<double*>(w);
+    if (!a.a_out) a.a_out = reinterpret_cast<double*>(w);
     const int cus = device_cus();
     int rc;
-    if (B > 4 * (int64_t)cus) {
-        rc = launch_sm_fwd<kTier0, 4, 2>(a, 0);
+    if (!SEQ && B > 4 * (int64_t)cus) {   // (the sequence factor, unused by the experiments, skips tier 0)
+        rc = launch_sm_fwd<kTier0, 4, 2, false>(a, 0);
         if (rc != SMLVM_OK) return rc;
-        rc = launch_sm_fwd<kTier1, 4, 2>(a, 1);
+        rc = launch_sm_fwd<kTier1, 4, 2, SEQ>(a, 1);
     } else {
-        rc = launch_sm_fwd<kTier1, 4, 2>(a, 0);
+        rc = launch_sm_fwd<kTier1, 4, 2, SEQ>(a, 0);
     }
     if (rc != SMLVM_OK) return rc;
-    if (n + 2 <= kTier2) return launch_sm_fwd<kTier2, 4, 2>(a, 1);
-    rc = launch_sm_fwd<kTier2, 4, 2>(a, 1);
+    if (n + 2 <= kTier2) return launch_sm_fwd<kTier2, 4, 2, SEQ>(a, 1);
+    rc = launch_sm_fwd<kTier2, 4, 2, SEQ>(a, 1);
     if (rc != SMLVM_OK) return rc;
-    return launch_sm_fwd<kTier3, 4, 2>(a, 1);
+    return launch_sm_fwd<kTier3, 4, 2, SEQ>(a, 1);
+}
+
+extern "C" int smlvm_sparsemap_fwd(const float* scores, const double* init_scores, int32_t budget,
+                                   int32_t max_iter, int64_t B, int32_t n, uint32_t* aset_bits,
+                                   float* p, int32_t* alen, double* inv_a, int32_t* iters,
+                                   int32_t* status, void* workspace, size_t workspace_bytes,
+                                   void* stream)
+{
+    if (B < 0 || n < 1 || max_iter < 0 || budget < 0) return SMLVM_ERR_INVALID;
+    if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
+    if (B == 0) return SMLVM_OK;
+    if (!scores || !aset_bits || !p || !alen) return SMLVM_ERR_INVALID;
+    SmArgs a{scores, nullptr, init_scores, budget, max_iter, B, n, aset_bits, p, alen, inv_a, iters,
+             status, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    return run_sm_fwd<false>(a, workspace, workspace_bytes);
+}
+
+extern "C" int smlvm_sparsemap_seq_fwd(const float* scores, const float* trans,
+                                       const double* init_scores, int32_t max_iter, int64_t B,
+                                       int32_t n, uint32_t* aset_bits, float* p, int32_t* alen,
+                                       double* inv_a, int32_t* iters, int32_t* status,
+                                       void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (B < 0 || n < 2 || max_iter < 0) return SMLVM_ERR_INVALID;
+    if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
+    if (B == 0) return SMLVM_OK;
+    if (!scores || !trans || !aset_bits || !p || !alen) return SMLVM_ERR_INVALID;
+    SmArgs a{scores, trans, init_scores, 0, max_iter, B, n, aset_bits, p, alen, inv_a, iters,
+             status, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream};
+    return run_sm_fwd<true>(a, workspace, workspace_bytes);
 }
 
 extern "C" int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, const int32_t* alen,
@@ -1092,6 +1288,21 @@ extern "C" int smlvm_sparsemap_bwd(const float* dp, const uint32_t* aset_bits, c
     const int cap = n + 1, W = (n + 31) / 32;
     const size_t lds = sizeof(double) * 2 * cap + sizeof(uint32_t) * (size_t)cap * W;
     hipLaunchKernelGGL(sparsemap_bwd_kernel, dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream,
-                       dp, aset_bits, alen, inv_a, B, n, dscores);
+                       dp, aset_bits, alen, inv_a, B, n, dscores, (float*)nullptr);
+    return check_launch();
+}
+
+extern "C" int smlvm_sparsemap_seq_bwd(const float* dp, const uint32_t* aset_bits,
+                                       const int32_t* alen, const double* inv_a, int64_t B,
+                                       int32_t n, float* dscores, float* dtrans, void* stream)
+{
+    if (B < 0 || n < 2) return SMLVM_ERR_INVALID;
+    if (n > SMLVM_SPARSEMAP_MAX_BITS) return SMLVM_ERR_UNSUPPORTED;
+    if (B == 0) return SMLVM_OK;
+    if (!dp || !aset_bits || !alen || !inv_a || !dscores || !dtrans) return SMLVM_ERR_INVALID;
+    const int cap = n + 1, W = (n + 31) / 32;
+    const size_t lds = sizeof(double) * 2 * cap + sizeof(uint32_t) * (size_t)cap * W;
+    hipLaunchKernelGGL(sparsemap_bwd_kernel, dim3((unsigned)B), dim3(64), lds, (hipStream_t)stream,
+                       dp, aset_bits, alen, inv_a, B, n, dscores, dtrans);
     return check_launch();
 }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
-    "smlvm_sparsemap_bwd",
+    "smlvm_sparsemap_bwd", "smlvm_sparsemap_seq_fwd", "smlvm_sparsemap_seq_bwd",
     "smlvm_unpack_configs",
     "smlvm_lowrank_ce_fwd", "smlvm_lowrank_ce_bwd_workspace_bytes", "smlvm_lowrank_ce_bwd",
     "smlvm_segmented_logsumexp",
@@ -336,6 +336,51 @@ def sparsemap_fwd(scores, init_scores=None, budget=0, max_iter=300):
             _p(out["iters"]), _p(out["status"]), _p(ws), ctypes.c_size_t(ws_bytes), _stream()),
             "smlvm_sparsemap_fwd")
     return out
+
+
+def sparsemap_seq_fwd(scores, trans, init_scores=None, max_iter=300):
+    """Binary sequence factor: scores [B,n] f32, trans [B,n-1] f32 edge potentials of the (1 -> 1)
+    transitions, init_scores [B,2n] f64 or None.  Same outputs as sparsemap_fwd."""
+    scores = _need_gpu(scores, torch.float32, "scores")
+    trans = _need_gpu(trans, torch.float32, "trans")
+    B, n = scores.shape
+    if tuple(trans.shape) != (B, n - 1):
+        raise ValueError("trans must be [B, n-1]")
+    cap, W, ld = n + 1, (n + 31) // 32, n + 2
+    dev = scores.device
+    if init_scores is not None:
+        init_scores = _need_gpu(init_scores, torch.float64, "init_scores")
+        if tuple(init_scores.shape) != (B, 2 * n):
+            raise ValueError("init_scores must be [B, 2n]")
+    out = dict(
+        aset_bits=torch.empty((B, cap, W), dtype=torch.int32, device=dev),
+        p=torch.empty((B, cap), dtype=torch.float32, device=dev),
+        alen=torch.empty(B, dtype=torch.int32, device=dev),
+        inv_a=torch.empty((B, ld, ld), dtype=torch.float64, device=dev),
+        iters=torch.empty(B, dtype=torch.int32, device=dev),
+        status=torch.empty(B, dtype=torch.int32, device=dev))
+    ws_bytes = lib().smlvm_sparsemap_fwd_workspace_bytes(B, n, 1)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_sparsemap_seq_fwd(
+            _p(scores), _p(trans), _p(init_scores), _i32(int(max_iter)), _i64(B), _i32(n),
+            _p(out["aset_bits"]), _p(out["p"]), _p(out["alen"]), _p(out["inv_a"]),
+            _p(out["iters"]), _p(out["status"]), _p(ws), ctypes.c_size_t(ws_bytes), _stream()),
+            "smlvm_sparsemap_seq_fwd")
+    return out
+
+
+def sparsemap_seq_bwd(dp, aset_bits, alen, inv_a, n):
+    """dp [B,n+1] f32 -> (dscores [B,n], dtrans [B,n-1]) f32."""
+    dp = _need_gpu(dp, torch.float32, "dp")
+    B = dp.shape[0]
+    dscores = torch.empty((B, n), dtype=torch.float32, device=dp.device)
+    dtrans = torch.empty((B, n - 1), dtype=torch.float32, device=dp.device)
+    with torch.cuda.device(dp.device):
+        _check(lib().smlvm_sparsemap_seq_bwd(_p(dp), _p(aset_bits), _p(alen), _p(inv_a), _i64(B),
+                                             _i32(n), _p(dscores), _p(dtrans), _stream()),
+               "smlvm_sparsemap_seq_bwd")
+    return dscores, dtrans
 
 
 def sparsemap_bwd(dp, aset_bits, alen, inv_a, n):

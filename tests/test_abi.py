@@ -60,6 +60,12 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_sparsemap_fwd(one, null, i32(-1), i32(10), i64(2), i32(16), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -1
     # n > 64 needs the tier workspace
     assert lib.smlvm_sparsemap_fwd(one, null, i32(0), i32(10), i64(2), i32(100), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -4
+    # the sequence factor: n >= 2, trans required, same size limits and workspace rule
+    assert lib.smlvm_sparsemap_seq_fwd(one, one, null, i32(10), i64(2), i32(1), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -1
+    assert lib.smlvm_sparsemap_seq_fwd(one, null, null, i32(10), i64(2), i32(16), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -1
+    assert lib.smlvm_sparsemap_seq_fwd(one, one, null, i32(10), i64(2), i32(129), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -2
+    assert lib.smlvm_sparsemap_seq_fwd(one, one, null, i32(10), i64(2), i32(100), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -4
+    assert lib.smlvm_sparsemap_seq_bwd(one, one, one, one, i64(2), i32(16), one, null, null) == -1
     lib.smlvm_sparsemap_fwd_workspace_bytes.restype = ctypes.c_size_t
     assert lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(64), i32(1)) == 0
     assert lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(128), i32(0)) > lib.smlvm_sparsemap_fwd_workspace_bytes(i64(8), i32(128), i32(1)) > 0

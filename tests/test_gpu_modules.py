@@ -197,8 +197,58 @@ def test_autograd_class_names(dev, oracle_mod):
     np.testing.assert_allclose(gx.cpu().numpy(), want, atol=1e-6)
     p2, aset2 = sm.BudgetSparseMAP.apply(x, 2, 100, False)
     assert torch.all(aset2.sum(-1) <= 2) and abs(float(p2.sum()) - 1) < 1e-6
-    with pytest.raises(NotImplementedError):
-        sm.sequence_smap(x, x[:-1])
+
+
+def test_sequence_smap_as_the_reference_drives_it(dev, oracle_mod):
+    """sequence_smap / SequenceBinarySparseMAP (sparsemap.py:47-87,130-148,159-160): p, aset and both
+    gradients against the oracle with the same init draw; then PFactorSequenceBinary through the
+    reference's own call sequence (initialize, set_additional_log_potentials,
+    init_active_set_from_scores(init, zeros), solve_qp(eta_u, eta_v), get_sparse_solution,
+    dist_jacobian_vec(dp, d_eta_u [2n], d_eta_v [n-1]))."""
+    from lvmhelpers import sparsemap as sm
+    from lvmhelpers.psequence import PFactorSequenceBinary
+    assert issubclass(sm.SequenceBinarySparseMAP, sm.SequenceSparseMAP)
+    n = 9
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, generator=g).to(dev).requires_grad_(True)
+    t = torch.randn(n - 1, generator=g).to(dev).requires_grad_(True)
+    torch.manual_seed(8)
+    p, aset = sm.sequence_smap(x, t)
+    assert not aset.requires_grad and aset.shape == (p.shape[0], n) and abs(float(p.sum()) - 1) < 1e-6
+    w = torch.randn(p.shape[0], generator=g).to(dev)
+    gx, gt = torch.autograd.grad((p * w).sum(), (x, t))
+    torch.manual_seed(8)
+    init = torch.rand(2 * n, dtype=torch.double).numpy()[None]
+    xn, tn = x.detach().cpu().numpy()[None], t.detach().cpu().numpy()[None]
+    ref = oracle_mod.sparsemap_seq_fwd(xn, tn, init, max_iter=100)
+    m = int(ref["alen"][0])
+    assert p.shape[0] == m and np.array_equal(p.detach().cpu().numpy(), ref["p"][0, :m])
+    assert np.array_equal(aset.cpu().numpy(), oracle_mod.unpack_bits(ref["aset_bits"], n)[0, :m])
+    dp = np.zeros((1, n + 1), np.float32)
+    dp[0, :m] = w.cpu().numpy()
+    ds, dt = oracle_mod.sparsemap_seq_bwd(dp, ref["aset_bits"], ref["alen"], ref["invA"], n)
+    np.testing.assert_allclose(gx.cpu().numpy(), ds[0], atol=1e-6)
+    np.testing.assert_allclose(gt.cpu().numpy(), dt[0], atol=1e-6)
+    # the factor object, as sparsemap.py:56-72,82-84 uses it
+    f = PFactorSequenceBinary()
+    f.initialize(n)
+    x_np = np.concatenate([xn[0].astype(np.double), np.zeros(n)])
+    t_np = tn[0].astype(np.double)
+    f.set_additional_log_potentials(t_np)
+    f.init_active_set_from_scores(torch.from_numpy(init[0]), torch.zeros(n - 1, dtype=torch.double))
+    post, add = f.solve_qp(x_np, t_np, max_iter=100)
+    aset_l, p_l = f.get_sparse_solution()
+    assert len(aset_l) == m and np.allclose(p_l[:m], ref["p"][0, :m])
+    A = np.asarray(aset_l, np.float64)
+    np.testing.assert_allclose(post[:n], (np.asarray(p_l)[:, None] * A).sum(0), atol=1e-7)
+    np.testing.assert_allclose(add, (np.asarray(p_l)[:, None] * A[:, :-1] * A[:, 1:]).sum(0), atol=1e-7)
+    d_eta_u = np.empty(2 * n, dtype=np.float32)
+    d_eta_v = np.empty(n - 1, dtype=np.float32)
+    f.dist_jacobian_vec(w.cpu().numpy(), d_eta_u, d_eta_v)
+    np.testing.assert_allclose(d_eta_u[:n], ds[0], atol=1e-6)
+    np.testing.assert_allclose(d_eta_v, dt[0], atol=1e-6)
+    with pytest.raises(ValueError):
+        sm.sequence_smap(x, t[:-1])
 
 
 def test_sparsemap_wrapper_is_world_size_independent(dev):

@@ -165,3 +165,82 @@ def test_marginals_closed_form_full_size(dev, oracle_mod, sigma, budget):
         mu_r = np.einsum("bc,bcn->bn", ref["p64"], bits_r)
         mu_c = np.clip((x[:nb].cpu().numpy().astype(np.float64) + 1) / 2, 0, 1)
         assert np.abs(mu_r - mu_c)[okr].max() <= 1e-9
+
+
+# ------------------------------------------------------------------ binary sequence factor
+def _seq_inputs(B, n, sigma, seed, kind="normal"):
+    rng = np.random.default_rng(seed)
+    x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+    t = (sigma * rng.standard_normal((B, n - 1))).astype(np.float32)
+    if kind == "degenerate":   # integers: ties in Viterbi, affinely dependent vertices (C8 swaps)
+        x, t = np.round(x), np.round(t)
+        x[0] = 0.0
+        t[1 % B] = 0.0
+    init = torch.rand(B, 2 * n, dtype=torch.double,
+                      generator=torch.Generator().manual_seed(43)).numpy()
+    return x, t, init
+
+
+SEQ_CASES = [(32, 2, 1.0, True), (32, 3, 2.0, False), (32, 8, 1.0, True), (32, 10, 3.0, False),
+             (64, 32, 1.0, True), (64, 32, 0.5, False), (16, 33, 1.0, True), (16, 64, 1.0, True),
+             (16, 65, 1.0, False), (24, 100, 2.0, True), (24, 128, 1.0, True), (16, 128, 0.5, False)]
+
+
+@pytest.mark.parametrize("kind", ["normal", "degenerate"])
+@pytest.mark.parametrize("B,n,sigma,use_init", SEQ_CASES)
+def test_sequence_factor_matches_oracle(dev, oracle_mod, B, n, sigma, use_init, kind):
+    """sequence_smap (lvmhelpers/sparsemap.py:47-87,130-148): Viterbi oracle, edge scores in
+    Evaluate, vertex swap on singular insertions -- active set, order, iterations, status, p and the
+    cached inverse identical to the fp64 oracle; both gradients within 1e-6."""
+    from lvmhelpers import _native
+    x, t, init = _seq_inputs(B, n, sigma, 31 * n + int(10 * sigma), kind)
+    ref = oracle_mod.sparsemap_seq_fwd(x, t, init if use_init else None, max_iter=300)
+    out = _native.sparsemap_seq_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev),
+                                    torch.from_numpy(init).to(dev) if use_init else None, 300)
+    alen = out["alen"].cpu().numpy()
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    assert np.array_equal(alen, ref["alen"])
+    assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    assert np.array_equal(out["p"].cpu().numpy(), ref["p"])
+    inv = out["inv_a"].cpu().numpy()
+    for b in range(B):
+        m = alen[b]
+        assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
+    rng = np.random.default_rng(6)
+    dp = rng.standard_normal((B, n + 1)).astype(np.float32)
+    ds_ref, dt_ref = oracle_mod.sparsemap_seq_bwd(dp, ref["aset_bits"], ref["alen"], ref["invA"], n)
+    ds, dt = _native.sparsemap_seq_bwd(torch.from_numpy(dp).to(dev), out["aset_bits"], out["alen"],
+                                       out["inv_a"], n)
+    np.testing.assert_allclose(ds.cpu().numpy(), ds_ref, rtol=1e-6,
+                               atol=1e-6 * max(1.0, np.abs(ds_ref).max()))
+    np.testing.assert_allclose(dt.cpu().numpy(), dt_ref, rtol=1e-6,
+                               atol=1e-6 * max(1.0, np.abs(dt_ref).max()))
+
+
+def test_sequence_factor_swaps_and_tiers(dev, oracle_mod):
+    """192 chains of 128 positions: active sets reach every LDS tier, and the batch contains
+    singular insertions (C8); still identical to the one-pass oracle.  With zero edge potentials
+    the factor is the Bernoulli factor: marginals clip((x+1)/2, 0, 1)."""
+    from lvmhelpers import _native
+    B, n = 192, 128
+    x, t, init = _seq_inputs(B, n, 1.0, 99)
+    t[::2] = np.round(t[::2])
+    ref = oracle_mod.sparsemap_seq_fwd(x, t, init, max_iter=300)
+    assert (ref["alen"] > 63).any() and (ref["alen"] <= 63).any()
+    out = _native.sparsemap_seq_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev),
+                                    torch.from_numpy(init).to(dev), 300)
+    for key_o, key_r in (("status", "status"), ("iters", "iters"), ("alen", "alen"), ("p", "p")):
+        assert np.array_equal(out[key_o].cpu().numpy(), ref[key_r]), key_o
+    assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    # zero edge potentials
+    z = np.zeros_like(t)
+    out0 = _native.sparsemap_seq_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(z).to(dev),
+                                     torch.from_numpy(init).to(dev), 300)
+    ok = (out0["status"] == 0).cpu().numpy()
+    assert ok.mean() > 0.8
+    k = torch.arange(n, device=dev)
+    bits = ((out0["aset_bits"][..., k // 32] >> (k % 32)) & 1).double()
+    mu = torch.einsum("bc,bcn->bn", out0["p"].double(), bits).cpu().numpy()
+    mu_ref = np.clip((x.astype(np.float64) + 1) / 2, 0, 1)
+    assert np.abs(mu - mu_ref)[ok].max() <= 1e-6
