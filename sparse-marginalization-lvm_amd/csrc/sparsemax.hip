@@ -663,6 +663,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
     int s_final = 1;
     double S_final = 0.0;
     bool fast = false;
+    // what the lazy steps leave for a full-width search: the bound they reached, and whether they
+    // stopped AT Michelot's fixed point (then the search starts with the edge, no iteration)
+    float full_tau = -1.0f;
+    bool full_fixed = false;
     if constexpr (CAND) {   // K <= 65536 < kCandMaxK in every kernel that comes through here
         const int lane = threadIdx.x & 63;
         float c[kCandPerLane];
@@ -674,10 +678,13 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             int n_c = compact_candidates<E, VEC>(z, floor_k, cand, kCandCap, ccols, colbase, colstep);
             if (n_c > kCandCap) {
                 float tau = subset_bound(lane_mx);
-                wave_lds_sync();
-                thr_used = fmaxf(tau - margin, floor_k);
-                tau_used = tau;
-                n_c = compact_candidates<E, VEC>(z, thr_used, cand, kCandCap, ccols, colbase, colstep);
+                // a cut that did not move selects the same (too many) candidates: not tried again
+                if (fmaxf(tau - margin, floor_k) > thr_used) {
+                    wave_lds_sync();
+                    thr_used = fmaxf(tau - margin, floor_k);
+                    tau_used = tau;
+                    n_c = compact_candidates<E, VEC>(z, thr_used, cand, kCandCap, ccols, colbase, colstep);
+                }
                 int cnt_prev = 0x7fffffff;
                 for (int pass = 0; n_c > kCandCap && pass < kLazyPasses; ++pass) {
                     int cn = 0;
@@ -689,10 +696,10 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                         sm += in ? z[e] : 0.0f;
                     }
                     red.cs(cn, sm);
-                    if (cn >= cnt_prev) break;   // fixed point with a wide support: full-width search
+                    if (cn >= cnt_prev) { full_fixed = true; break; }   // fixed point, wide support: full-width search
                     cnt_prev = cn;
                     tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
-                    if (cn <= kLazyTry) {
+                    if (cn <= kLazyTry && fmaxf(tau - margin, floor_k) > thr_used) {
                         wave_lds_sync();
                         thr_used = fmaxf(tau - margin, floor_k);
                         tau_used = tau;
@@ -701,6 +708,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                         if (n_c <= kCandCap) break;
                     }
                 }
+                full_tau = tau;   // a lower bound of the threshold (the full-width search starts there)
             }
             fast = n_c <= kCandCap;
             if (fast) {
@@ -719,7 +727,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             int* ccols = list ? cnt + NW : nullptr;   // NW*64 candidate columns after the counts
             // candidates above the floor first; if they do not fit (narrow logit distribution),
             // block-wide Michelot steps raise the bound and the compaction is tried again above it
-            float thr = floor_k, tau = -1.0f;
+            float thr = floor_k, tau = -1.0f, thr_tried = -INFINITY;
             bool first = true;
             int cnt_prev = 0x7fffffff, passes = 0;
             // every lane's maximum, parked for the refinement of the bound after a first failure
@@ -729,7 +737,9 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 // a wave in which every lane holds an element above the cut has at least 64 of them:
                 // its 64-entry list would have no room to spare, so it does not even try (narrow
                 // logit distributions: saves the 64 ballots of a compaction that cannot succeed)
-                const bool crowded = first && __ballot(lane_mx > thr) == ~0ull;
+                // (nor does it try the same cut twice)
+                const bool crowded = __ballot(lane_mx > thr) == ~0ull || !(thr > thr_tried);
+                thr_tried = thr;
                 const int n_w = crowded ? 65
                                         : compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
                                                                      ccols ? ccols + wave * 64 : nullptr,
@@ -807,11 +817,13 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                         sm += in ? z[e] : 0.0f;
                     }
                     red.cs(cn, sm);
-                    if (cn >= cnt_prev || ++passes > kLazyPasses) { give_up = true; break; }
+                    if (cn >= cnt_prev) { give_up = true; full_fixed = true; break; }
+                    if (++passes > kLazyPasses) { give_up = true; break; }
                     cnt_prev = cn;
                     tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
                     if (cn <= kLazyTry) break;
                 }
+                full_tau = tau;
                 if (give_up) break;
                 thr = fmaxf(tau - margin, floor_k);
             }
@@ -831,7 +843,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             }
         }
     }
-    if (__builtin_expect(!fast, 0)) solve_core(z, red, K, s_final, S_final);
+    if (__builtin_expect(!fast, 0)) solve_core(z, red, K, s_final, S_final, nullptr, full_tau, full_fixed);
 
     float c_s = (float)S_final - 1.0f;
     float tau_f = c_s / (float)s_final;
@@ -1310,6 +1322,17 @@ __device__ __forceinline__ unsigned xcd_block()
     const unsigned xcd = b & 7u;
     return xcd * per + ((b >> 3) + xcd * 17u) % per;
 }
+// Workgroups that fill a CU keep the plain order (neighbouring rows in flight together), but a
+// workgroup's XCD is blockIdx % 8 whatever the XCDs are doing: rows whose cost has a period that
+// divides 8 (bench.py's adversarial mix repeats every 4 rows) would land all the expensive ones on
+// the same two XCDs and the launch takes as long as those (K = 65536: 6.2 ms for a mix whose kinds
+// average 4.2 ms).  Rotating the rows of every aligned group of eight by the group's index hands
+// each XCD every residue in turn; the same eight rows are in flight at the same time as before.
+__device__ __forceinline__ int64_t rot8(int64_t row, int64_t R)
+{
+    if ((row | 7) >= R) return row;
+    return (row & ~(int64_t)7) | ((row + (row >> 3)) & 7);
+}
 // First row of this lane's group.  One row per wave (G == 64): the wave index goes through
 // readfirstlane so that the row, its base addresses and `live` are scalar -- loads and stores then
 // use the SGPR-base + 32-bit-lane-offset form instead of sixteen 64-bit VGPR addresses per tensor
@@ -1422,7 +1445,8 @@ __global__ __launch_bounds__(64 * NW, 4) void sparsemax_fwd_block_kernel(
     __shared__ float cand[3 * NW * 64 + NW];   // candidate values, counts, columns, lane maxima
     // XCD-aware row order for the small workgroups (K = 16384 forward 1.45 -> 1.37 ms; neutral at
     // NW = 8, a loss at NW = 16 where one workgroup fills the CU)
-    for (int64_t row = xcd_block<(NW <= 4)>(); row < R; row += gridDim.x) {
+    for (int64_t row0 = xcd_block<(NW <= 4)>(); row0 < R; row0 += gridDim.x) {
+        const int64_t row = NW <= 4 ? row0 : rot8(row0, R);
         float z[E];
         load_row<E, VEC, FULL, true>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
@@ -1622,7 +1646,8 @@ __global__ __launch_bounds__(64 * NW) void sparsemax_bwd_block_kernel(
     float* __restrict__ dx, int64_t R, int K, const int32_t* __restrict__ cols, int cap)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+    for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
+        const int64_t row = rot8(row0, R);   // (see rot8: periodic row costs and the XCD round robin)
         if (cols && cols[row * cap] != kColsOverflow) continue;   // done from its list (block-uniform)
         const int s = supp[row];   // block-uniform
         BlockRed<NW> red(lds);
@@ -1725,7 +1750,8 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_fwd_stream_kernel(
     int* cnt = reinterpret_cast<int*>(cand + NW * 64);
     int* ccols = cnt + NW;
     const int nstep = VEC ? (K >> 2) : K;   // float4 chunks or elements per row
-    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+    for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
+        const int64_t row = rot8(row0, R);
         const float* xr = x + row * K;
         BlockRed<NW> red(lds);
         float lm = -INFINITY;
@@ -1902,7 +1928,8 @@ __global__ __launch_bounds__(64 * kStreamNW) void sparsemax_bwd_stream_kernel(
 {
     constexpr int NW = kStreamNW, NT = 64 * NW;
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+    for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
+        const int64_t row = rot8(row0, R);
         if (cols && cols[row * cap] >= kColsNone) continue;   // block-uniform
         BlockRed<NW> red(lds);
         const float* pr = p + row * K;
@@ -2202,7 +2229,8 @@ __global__ __launch_bounds__(64 * NW, 4) void entmax15_fwd_block_kernel(
     float* __restrict__ tau, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+    for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
+        const int64_t row = rot8(row0, R);
         float z[E];
         load_row<E, VEC, FULL, true>(x + row * K, K, threadIdx.x, 64 * NW, z, -INFINITY);
         BlockRed<NW> red(lds);
@@ -2239,7 +2267,8 @@ __global__ __launch_bounds__(64 * NW) void entmax15_bwd_block_kernel(
     const float* __restrict__ dy, const float* __restrict__ p, float* __restrict__ dx, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    for (int64_t row = blockIdx.x; row < R; row += gridDim.x) {
+    for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
+        const int64_t row = rot8(row0, R);
         float g[E], y[E];
         load_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, y, 0.0f);
         load_row<E, VEC, FULL, true>(dy + row * K, K, threadIdx.x, 64 * NW, g, 0.0f);
