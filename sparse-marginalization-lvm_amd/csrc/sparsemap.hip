@@ -69,17 +69,25 @@ __device__ __forceinline__ void wsync() { __syncthreads(); }  // single-wave wor
 
 // Diagnostic build only (tools/sm_prof.hip defines SMLVM_SM_PROF): cycles per solver phase.
 #ifdef SMLVM_SM_PROF
-__device__ unsigned long long g_prof[16];
+// per-sample phase times: accumulated in registers, written once at the end of the kernel
+// (g_prof_out [B][16] device memory, accumulated over the tiers of a sample)
+__device__ unsigned long long* g_prof_out;
 #define SM_T(k)                                                                   \
     do {                                                                          \
         long long now_ = clock64();                                               \
-        if (threadIdx.x == 0) atomicAdd(&g_prof[k], (unsigned long long)(now_ - t_last_)); \
+        prof_acc_[k] += (unsigned long long)(now_ - t_last_);                     \
         t_last_ = now_;                                                           \
     } while (0)
-#define SM_T0() long long t_last_ = clock64()
+#define SM_T0() unsigned long long prof_acc_[16] = {0}; long long t_last_ = clock64()
+#define SM_TEND(s_)                                                               \
+    do {                                                                          \
+        if (threadIdx.x == 0 && g_prof_out)                                       \
+            for (int k_ = 0; k_ < 16; ++k_) g_prof_out[(s_) * 16 + k_] += prof_acc_[k_]; \
+    } while (0)
 #else
 #define SM_T(k) do { } while (0)
 #define SM_T0() do { } while (0)
+#define SM_TEND(s_) do { } while (0)
 #endif
 
 // Every lane holds the same bits; tell the compiler (scalar registers, scalar branches).
@@ -165,6 +173,84 @@ __device__ __forceinline__ double matvec_col(const double* col, const double* b,
         if (j0 >= cnt8) break;
     }
     return acc;
+}
+
+// The same for NQ columns at once (lane c, c + 64, ...: the chunks of a matrix-vector product):
+// NQ independent chains advance together, so a step costs an issue slot instead of the latency of
+// a dependent v_add_f64 (a lone wave per SIMD has nothing else to hide it with).  Each chain adds
+// the same numbers in the same order as matvec_col.
+template <int LD, int NQ>
+__device__ __forceinline__ void matvec_cols(const double* const (&col)[NQ], const double* b, int cnt8,
+                                            double (&acc)[NQ])
+{
+    double a0[NQ][8], a1[NQ][8], b0[8], b1[8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        acc[q] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[q][u] = col[q][u * LD];
+    }
+    ld8(b, b0);
+    int j0 = 0;
+    for (;;) {
+        int jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a1[q][u] = col[q][(jn + u) * LD];
+        ld8(b + jn, b1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const double t = a0[q][u] * b0[u]; acc[q] += t; }
+        j0 += 8;
+        if (j0 >= cnt8) break;
+        jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a0[q][u] = col[q][(jn + u) * LD];
+        ld8(b + jn, b0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const double t = a1[q][u] * b1[u]; acc[q] += t; }
+        j0 += 8;
+        if (j0 >= cnt8) break;
+    }
+}
+
+// out[q] = sum_{j < cnt8} A[j][c_q] rhs[j] for this lane's columns c_q = lane + 64 q of the chunks
+// that hold an output or padding to clear (q 64 <= cnt8, c_q < NA); columns beyond LD - 1 read the
+// last one (their result is discarded).  Returns the number of chunks computed.
+template <int LD, int NA>
+__device__ __forceinline__ int matvec_chunks(const double* A, const double* rhs, int cnt8, int lane,
+                                             double (&out)[(NA + 63) / 64])
+{
+    constexpr int NQ = (NA + 63) / 64;
+    static_assert(NQ <= 3, "at most three 64-lane chunks (n <= 128)");
+    int nq = cnt8 / 64 + 1;
+    nq = nq < NQ ? nq : NQ;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) out[q] = 0.0;
+    auto colp = [&](int q) { const int c = lane + 64 * q; return A + (c < LD ? c : LD - 1); };
+    if (NQ == 1 || nq == 1) {
+        out[0] = matvec_col<LD>(colp(0), rhs, cnt8);
+    } else if (NQ == 2 || nq == 2) {
+        const double* const col[2] = {colp(0), colp(1)};
+        double acc[2];
+        matvec_cols<LD, 2>(col, rhs, cnt8, acc);
+        out[0] = acc[0];
+        if constexpr (NQ >= 2) out[1] = acc[1];
+    } else {
+        const double* const col[3] = {colp(0), colp(1), colp(2)};
+        double acc[3];
+        matvec_cols<LD, 3>(col, rhs, cnt8, acc);
+        out[0] = acc[0];
+        if constexpr (NQ >= 2) out[1] = acc[1];
+        if constexpr (NQ >= 3) out[2] = acc[2];
+    }
+    return nq;
 }
 
 __device__ __forceinline__ double f64_from_hi(int hi)
@@ -702,12 +788,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     auto kkt_apply = [&](const double* rhs, bool accumulate) {
         const int cnt8 = round8(m + 1);
         double t0 = 0.0;
+        double mv[(L::NA + 63) / 64];
+        matvec_chunks<LD, L::NA>(A, rhs, cnt8, lane, mv);
 #pragma unroll
         for (int q = 0; q * 64 < L::NA; ++q) {
             const int c = lane + 64 * q;
             if (q * 64 <= cnt8) {   // uniform: chunks that hold an output or padding to clear
-                const int cc = c < LD ? c : LD - 1;
-                const double acc = matvec_col<LD>(A + cc, rhs, cnt8);
+                const double acc = mv[q];
                 if (c == 0) t0 = acc;
                 else if (c - 1 < L::NA) {
                     if (accumulate) { if (c <= m) z[c - 1] = z[c - 1] + acc; }
@@ -729,31 +816,41 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             if (i != ri) d[i - (i > ri ? 1 : 0)] = -sdiv * A[ri * LD + i];
         wsync();
         // in place with compaction: targets never pass the sources in row-major order.
-        // Rows go in batches of 4: all reads of a batch are issued before its writes (one
-        // wave: LDS executes in order), and a batch only writes rows it has already read.
-        for (int i0 = 0; i0 <= m; i0 += 4) {
+        // Rows go in batches of 8, all column chunks together: all reads of a batch are issued
+        // before its writes (one wave: LDS executes in order), and a batch only writes rows it has
+        // already read.  (Batches of 4 rows, chunk by chunk, exposed the LDS round trip 3 m / 4
+        // times per removal: 30 % of the run time of the samples that zigzag to the iteration limit.)
+        constexpr int RB = 8, NQA = (LD + 63) / 64;
+        bool okj[NQA];
+        int lq[NQA];
+        double dl[NQA];
 #pragma unroll
-            for (int q = 0; q * 64 < LD; ++q) {
-                const int j = lane + 64 * q;
-                const bool okj = (j <= m) && (j != ri);
-                const int l = j - (j > ri ? 1 : 0);
-                double v[4], dk[4];
-                const double dl = okj ? d[l] : 0.0;
+        for (int q = 0; q < NQA; ++q) {
+            const int j = lane + 64 * q;
+            okj[q] = (j <= m) && (j != ri);
+            lq[q] = j - (j > ri ? 1 : 0);
+            dl[q] = okj[q] ? d[lq[q]] : 0.0;
+        }
+        for (int i0 = 0; i0 <= m; i0 += RB) {
+            double v[NQA][RB], dk[RB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    const int ic = i <= m ? i : m;
-                    const int kk = ic - (ic > ri ? 1 : 0);
-                    v[u] = okj ? A[ic * LD + j] : 0.0;
-                    dk[u] = d[kk];
-                }
+            for (int u = 0; u < RB; ++u) {
+                const int i = i0 + u;
+                const int ic = i <= m ? i : m;
+                const int kk = ic - (ic > ri ? 1 : 0);
+                dk[u] = d[kk];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    if (okj && i <= m && i != ri) {
-                        const int kk = i - (i > ri ? 1 : 0);
-                        A[kk * LD + l] = v[u] - invs * dk[u] * dl;
-                    }
+                for (int q = 0; q < NQA; ++q)
+                    if (q * 64 <= m) v[q][u] = okj[q] ? A[ic * LD + lane + 64 * q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int i = i0 + u;
+                if (i <= m && i != ri) {
+                    const int kk = i - (i > ri ? 1 : 0);
+#pragma unroll
+                    for (int q = 0; q < NQA; ++q)
+                        if (q * 64 <= m && okj[q]) A[kk * LD + lq[q]] = v[q][u] - invs * dk[u] * dl[q];
                 }
             }
         }
@@ -806,12 +903,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     auto insertion_direction = [&]() -> double {
         wsync();
         const int cnt8 = round8(m + 1);
+        double mv[(L::NA + 63) / 64];
+        matvec_chunks<LD, L::NA>(A, r, cnt8, lane, mv);
 #pragma unroll
         for (int q = 0; q * 64 < L::NA; ++q) {
             const int j = lane + 64 * q;
             if (q * 64 <= cnt8 && j < L::NA) {
-                const int jj = j < LD ? j : LD - 1;
-                const double acc = matvec_col<LD>(A + jj, r, cnt8);
+                const double acc = mv[q];
                 const double dj = (j <= m) ? acc : 0.0;
                 d[j] = dj;
                 prod[j] = r[j] * dj;   // r is 0 beyond m
@@ -971,22 +1069,34 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             wsync();
             SM_T(5);
             // A[i][j] += (invs d_i) d_j : lane owns column j
+            {   // (the column chunks of an 8-row batch together: one LDS round trip per batch)
+                constexpr int NQA = (LD + 63) / 64;
+                double dj[NQA];
+                bool on[NQA];
 #pragma unroll
-            for (int q = 0; q * 64 < LD; ++q) {
-                const int j = lane + 64 * q;
-                if (j <= m) {
-                    const double dj = d[j];
-                    double* col = A + j;
-                    for (int i0 = 0; i0 < cnt8; i0 += 8) {
-                        double a[8], t[8];
+                for (int q = 0; q < NQA; ++q) {
+                    const int j = lane + 64 * q;
+                    on[q] = j <= m;
+                    dj[q] = on[q] ? d[j] : 0.0;
+                }
+                for (int i0 = 0; i0 < cnt8; i0 += 8) {
+                    double a[NQA][8], t[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) a[u] = col[(i0 + u) * LD];
-                        ld8(t1 + i0, t);
+                    for (int q = 0; q < NQA; ++q)
+                        if (q * 64 <= m && on[q]) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { const double pr = t[u] * dj; a[u] = a[u] + pr; }
+                            for (int u = 0; u < 8; ++u) a[q][u] = A[(i0 + u) * LD + lane + 64 * q];
+                        }
+                    ld8(t1 + i0, t);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) col[(i0 + u) * LD] = a[u];
-                    }
+                    for (int q = 0; q < NQA; ++q)
+                        if (q * 64 <= m && on[q]) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double pr = t[u] * dj[q];
+                                A[(i0 + u) * LD + lane + 64 * q] = a[q][u] + pr;
+                            }
+                        }
                 }
             }
             wsync();
@@ -1072,6 +1182,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             vo[2 * ldo + i] = bsc[i];
         }
     }
+    SM_TEND(s);
     if (lane == 0) {
         alen[s] = m;
         if (iters) iters[s] = it;

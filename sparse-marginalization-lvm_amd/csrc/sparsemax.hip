@@ -1990,6 +1990,7 @@ static unsigned wave_grid(int64_t R, int G)
 }
 static unsigned block_grid(int64_t R) { return (unsigned)(R < 65536 ? R : 65536); }
 
+
 template <int G, int E, bool VEC, bool FULL, bool EXTRA>
 static void fwd_wave_go(const FwdArgs& a)
 {

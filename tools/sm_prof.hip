@@ -27,28 +27,37 @@ int main(int argc, char** argv)
     hipMemcpy(dinit, init.data(), init.size() * 8, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 2; ++rep) {
 #ifdef SMLVM_SM_PROF
-        unsigned long long zero[16] = {0};
-        hipMemcpyToSymbol(HIP_SYMBOL(smlvm::g_prof), zero, sizeof zero);
+        static unsigned long long* dprof = nullptr;
+        if (!dprof) {
+            hipMalloc(&dprof, (size_t)B * 16 * 8);
+            hipMemcpyToSymbol(HIP_SYMBOL(smlvm::g_prof_out), &dprof, sizeof dprof);
+        }
+        hipMemset(dprof, 0, (size_t)B * 16 * 8);
 #endif
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         int rc = smlvm_sparsemap_fwd(dx, dinit, budget, 300, B, n, dbits, dp, dalen, dinv, dit, dst, dws, wsb, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        unsigned long long prof[16] = {0};
-#ifdef SMLVM_SM_PROF
-        hipMemcpyFromSymbol(prof, HIP_SYMBOL(smlvm::g_prof), sizeof prof);
-#endif
         std::vector<int> it(B); hipMemcpy(it.data(), dit, B * 4, hipMemcpyDeviceToHost);
-        long long tot = 0; for (int v : it) tot += v;
-        printf("rc=%d  %.3f ms  total iters %lld\n", rc, ms, tot);
-#ifndef SMLVM_SM_PROF
-        continue;
-#endif
+        long long tot = 0; int itmax = 0; for (int v : it) { tot += v; itmax = v > itmax ? v : itmax; }
+        printf("rc=%d  %.3f ms  total iters %lld  max %d\n", rc, ms, tot, itmax);
+#ifdef SMLVM_SM_PROF
+        std::vector<unsigned long long> pr((size_t)B * 16);
+        hipMemcpy(pr.data(), dprof, pr.size() * 8, hipMemcpyDeviceToHost);
         const char* names[] = {"solve z", "marginals", "maximize+eval", "dup+r+push", "d=invA r", "sden+t1", "A update+append", "C7 polish", "blocking(no)", "blocking+removal"};
-        unsigned long long sum = 0; for (int k = 0; k < 10; ++k) sum += prof[k];
-        for (int k = 0; k < 10; ++k) printf("  %-18s %12llu ticks  %5.1f%%\n", names[k], prof[k], 100.0 * prof[k] / sum);
-        printf("  ticks per iter: %.0f (clock64 = 100 MHz wall clock on gfx9?)\n", (double)sum / tot);
+        for (int pass = 0; pass < 2; ++pass) {   // all samples, then only the ones that ran longest
+            unsigned long long prof[16] = {0}; long long its = 0; int cnt = 0;
+            for (int b = 0; b < B; ++b) {
+                if (pass == 1 && it[b] < itmax) continue;
+                for (int k = 0; k < 16; ++k) prof[k] += pr[(size_t)b * 16 + k];
+                its += it[b]; ++cnt;
+            }
+            unsigned long long sum = 0; for (int k = 0; k < 10; ++k) sum += prof[k];
+            printf(" %s: %d samples, %lld passes, %.0f ticks per pass, %.0f ticks per sample\n", pass ? "longest" : "all", cnt, its, (double)sum / its, (double)sum / cnt);
+            for (int k = 0; k < 10; ++k) printf("  %-18s %14llu ticks  %5.1f%%\n", names[k], prof[k], 100.0 * prof[k] / sum);
+        }
+#endif
     }
     return 0;
 }
