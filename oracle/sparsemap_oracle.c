@@ -22,15 +22,26 @@
  * PARITY UNPINNED for the solver path: the reference holds no tests or golden vectors at this
  * boundary. The optimal marginals are unique, the decomposition into vertices is path dependent;
  * the choices that fix the path are listed here so the HIP kernel can follow them bit for bit:
- *   C1  every inner product below is a serial left-to-right fp64 loop, no FMA contraction
- *       (build with -ffp-contract=off);
+ *   C1  no FMA contraction (build with -ffp-contract=off); the long sums that sit on the solver's
+ *       critical path are accumulated in interleaved partial sums, the order a vectorised dot
+ *       product takes (upstream's are Eigen's packet reductions, not a scalar loop either):
+ *         - the matrix-vector products [tau; z] = invA^T b and d = invA r, one output per GPU lane:
+ *           EIGHT partials (term j goes to partial j mod 8, each left to right), combined as
+ *           ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) -- eight independent chains instead of one dependent
+ *           chain of up to n+2 additions;
+ *         - the sums that produce ONE scalar from a vector spread over the lanes -- the linear
+ *           oracle's value, Evaluate, s = n - r.d --: SIXTY-FOUR partials (term j goes to partial
+ *           j mod 64, each left to right: lane j mod 64 of the wave) combined by a balanced binary
+ *           tree over adjacent pairs (the wave's DPP reduction);
+ *       the marginals, the rows of the KKT residual (C7) and the Jacobian products stay serial
+ *       left to right;
  *   C2  after each change of the active set the KKT system is solved with the cached inverse:
  *       [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)];
  *   C3  an iteration that did not change the set computes marginals mu = sum_i z_i cfg_i in
  *       active-set order, calls the oracle on eta - mu, stops if value <= tau + 1e-9 or if the
  *       returned configuration is already active, else inserts it;
  *   C4  insertion: r = [1; common(cfg_i,new)], d = invA r (terms with r_i == 0 skipped),
- *       s = n - sum_j r_j d_j (serial; upstream uses a triangular double loop -- algebraically
+ *       s = n - sum_j r_j d_j (upstream uses a triangular double loop -- algebraically
  *       identical, rounding differs), |s| <= 1e-9 => status SINGULAR and stop (upstream removes a
  *       null-space configuration via an eigendecomposition; unreachable in exact arithmetic since
  *       insertion only follows an equality-constrained optimum);
@@ -77,6 +88,28 @@ enum { SM_CONVERGED = 0, SM_MAXITER = 1, SM_SINGULAR = 2, SM_DUPLICATE = 3, SM_S
 
 static inline int bit_of(const uint32_t* cfg, int k) { return (cfg[k >> 5] >> (k & 31)) & 1u; }
 
+/* C1: sixty-four interleaved partial sums, combined by a balanced tree over adjacent pairs */
+typedef struct { double p[64]; } sum64_t;
+static inline void sum64_zero(sum64_t* a) { for (int u = 0; u < 64; ++u) a->p[u] = 0.0; }
+static inline void sum64_add(sum64_t* a, int j, double v) { a->p[j & 63] += v; }
+static inline double sum64_get(const sum64_t* a)
+{
+    double t[64];
+    for (int u = 0; u < 64; ++u) t[u] = a->p[u];
+    for (int w = 1; w < 64; w <<= 1)
+        for (int i = 0; i < 64; i += 2 * w) t[i] = t[i] + t[i + w];
+    return t[0];
+}
+
+/* C1: eight interleaved partial sums, combined pairwise */
+typedef struct { double p[8]; } sum8_t;
+static inline void sum8_zero(sum8_t* a) { for (int u = 0; u < 8; ++u) a->p[u] = 0.0; }
+static inline void sum8_add(sum8_t* a, int j, double v) { a->p[j & 7] += v; }
+static inline double sum8_get(const sum8_t* a)
+{
+    return ((a->p[0] + a->p[1]) + (a->p[2] + a->p[3])) + ((a->p[4] + a->p[5]) + (a->p[6] + a->p[7]));
+}
+
 /* Linear oracle. on[k], off[k] potentials; fills cfg (W words) and returns the value.
  * budget <= 0: Bernoulli (bernoulli.h:14-35); budget > 0: budget.h:24-85. */
 static double maximize(const double* on, const double* off, int n, int budget, uint32_t* cfg,
@@ -84,20 +117,20 @@ static double maximize(const double* on, const double* off, int n, int budget, u
 {
     const int W = SM_WORDS(n);
     memset(cfg, 0, sizeof(uint32_t) * (size_t)W);
+    sum64_t value, sum;
+    sum64_zero(&value);
     if (budget <= 0) {
-        double value = 0.0;
         for (int i = 0; i < n; ++i) {
-            if (on[i] > off[i]) { cfg[i >> 5] |= 1u << (i & 31); value += on[i]; }
-            else value += off[i];
+            if (on[i] > off[i]) { cfg[i >> 5] |= 1u << (i & 31); sum64_add(&value, i, on[i]); }
+            else sum64_add(&value, i, off[i]);
         }
-        return value;
+        return sum64_get(&value);
     }
-    double value = 0.0;
-    for (int i = 0; i < n; ++i) { e_tmp[i] = on[i] - off[i]; value += off[i]; }
+    for (int i = 0; i < n; ++i) { e_tmp[i] = on[i] - off[i]; sum64_add(&value, i, off[i]); }
     int num_active = 0;
-    double sum = 0.0;
+    sum64_zero(&sum);
     for (int i = 0; i < n; ++i)
-        if (e_tmp[i] > 0) { sum += e_tmp[i]; cfg[i >> 5] |= 1u << (i & 31); ++num_active; }
+        if (e_tmp[i] > 0) { sum64_add(&sum, i, e_tmp[i]); cfg[i >> 5] |= 1u << (i & 31); ++num_active; }
     if (num_active > budget) {
         /* sort (-e, i) ascending == e descending, ties by smaller index (pairs are distinct so
          * std::sort's result is unique): insertion sort is enough for n <= 512 */
@@ -116,13 +149,13 @@ static double maximize(const double* on, const double* off, int n, int budget, u
             idx_tmp[j + 1] = v;
         }
         num_active = 0;
-        sum = 0.0;
+        sum64_zero(&sum);
         for (int k = 0; k < budget; ++k) {
             double valaux = e_tmp[idx_tmp[k]]; /* = -scores[k].first */
             if (valaux < 0) break;
             int i = idx_tmp[k];
             cfg[i >> 5] |= 1u << (i & 31);
-            sum += valaux;
+            sum64_add(&sum, k, valaux);   /* partial by rank */
             ++num_active;
         }
         for (int k = num_active; k < n; ++k) {
@@ -130,7 +163,7 @@ static double maximize(const double* on, const double* off, int n, int budget, u
             cfg[i >> 5] &= ~(1u << (i & 31));
         }
     }
-    return value + sum;
+    return sum64_get(&value) + sum64_get(&sum);
 }
 
 /* Linear oracle of the binary sequence factor (lvmhelpers/sequence_binary.h:11-38 on
@@ -171,12 +204,14 @@ static double maximize_seq(const double* on, const double* off, const double* t,
  * whenever bits k-1 and k are both on. */
 static double evaluate_cfg(const uint32_t* cfg, const double* eta, const double* t, int n)
 {
-    double v = 0.0;
+    sum64_t v;   /* C1; the sequence factor's terms are numbered node 2k, edge 2k+1 */
+    sum64_zero(&v);
     for (int k = 0; k < n; ++k) {
-        v += bit_of(cfg, k) ? eta[k] : 0.0;
-        if (t) v += (k > 0 && bit_of(cfg, k - 1) && bit_of(cfg, k)) ? t[k - 1] : 0.0;
+        if (!t) { sum64_add(&v, k, bit_of(cfg, k) ? eta[k] : 0.0); continue; }
+        sum64_add(&v, 2 * k, bit_of(cfg, k) ? eta[k] : 0.0);
+        sum64_add(&v, 2 * k + 1, (k > 0 && bit_of(cfg, k - 1) && bit_of(cfg, k)) ? t[k - 1] : 0.0);
     }
-    return v;
+    return sum64_get(&v);
 }
 
 static int common_values(const uint32_t* a, const uint32_t* b, int n)
@@ -318,8 +353,10 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                 for (int i = 0; i < m; ++i) /* Evaluate under eta = [x; 0] (and the edge potentials) */
                     bvec[i + 1] = evaluate_cfg(cfg + i * W, eta, trans ? tr : NULL, n);
                 for (int c = 0; c <= m; ++c) {
-                    double acc = 0.0;
-                    for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
+                    sum8_t acc8;
+                    sum8_zero(&acc8);
+                    for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * bvec[j]);
+                    const double acc = sum8_get(&acc8);
                     if (c == 0) tau = acc; else z[c - 1] = acc;
                 }
                 same = 0;
@@ -339,8 +376,10 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                     double rho = rho0;
                     for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
                         for (int c = 0; c <= m; ++c) { /* [dtau; dz] = invA^T res */
-                            double acc = 0.0;
-                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
+                            sum8_t acc8;
+                            sum8_zero(&acc8);
+                            for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * r[j]);
+                            const double acc = sum8_get(&acc8);
                             if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
                         }
                         rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
@@ -350,15 +389,19 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                         rebuild_inverse(A, ld, cfg, m, n, d, e_res);
                         ++rebuilds;
                         for (int c = 0; c <= m; ++c) {
-                            double acc = 0.0;
-                            for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * bvec[j];
+                            sum8_t acc8;
+                            sum8_zero(&acc8);
+                            for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * bvec[j]);
+                            const double acc = sum8_get(&acc8);
                             if (c == 0) tau = acc; else z[c - 1] = acc;
                         }
                         rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
                         for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
                             for (int c = 0; c <= m; ++c) {
-                                double acc = 0.0;
-                                for (int j = 0; j <= m; ++j) acc += A[j * ld + c] * r[j];
+                                sum8_t acc8;
+                                sum8_zero(&acc8);
+                                for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * r[j]);
+                                const double acc = sum8_get(&acc8);
                                 if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
                             }
                             rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
@@ -388,12 +431,15 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                 r[0] = 1.0;
                 for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
                 for (int j = 0; j <= m; ++j) {
-                    double acc = 0.0;
-                    for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; acc += A[i * ld + j] * r[i]; }
-                    d[j] = acc;
+                    sum8_t acc8;
+                    sum8_zero(&acc8);
+                    for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; sum8_add(&acc8, i, A[i * ld + j] * r[i]); }
+                    d[j] = sum8_get(&acc8);
                 }
-                double s = (double)n;
-                for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
+                sum64_t rd64;
+                sum64_zero(&rd64);
+                for (int j = 0; j <= m; ++j) sum64_add(&rd64, j, r[j] * d[j]);
+                double s = (double)n - sum64_get(&rd64);
                 double w_new = 0.0;   /* weight the new vertex starts with */
                 if (s <= 1e-9 && s >= -1e-9) {
                     if (!trans) { st = SM_SINGULAR; break; }
@@ -442,12 +488,14 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                     r[0] = 1.0;
                     for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
                     for (int j = 0; j <= m; ++j) {
-                        double acc = 0.0;
-                        for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; acc += A[i * ld + j] * r[i]; }
-                        d[j] = acc;
+                        sum8_t acc8;
+                        sum8_zero(&acc8);
+                        for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; sum8_add(&acc8, i, A[i * ld + j] * r[i]); }
+                        d[j] = sum8_get(&acc8);
                     }
-                    s = (double)n;
-                    for (int j = 0; j <= m; ++j) s -= r[j] * d[j];
+                    sum64_zero(&rd64);
+                    for (int j = 0; j <= m; ++j) sum64_add(&rd64, j, r[j] * d[j]);
+                    s = (double)n - sum64_get(&rd64);
                     if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
                     w_new = theta;
                 } else if (m >= cap) { /* a full set that rounding calls independent: no room */

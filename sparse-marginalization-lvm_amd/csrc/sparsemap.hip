@@ -6,19 +6,21 @@
 // oracles of lvmhelpers/bernoulli.h:14-35 (Bernoulli) and lvmhelpers/budget.h:24-85 (budget), and
 // lvmhelpers/sparsemap.py:38-44 (dist_jacobian_vec) for the backward.
 //
-// The arithmetic follows oracle/sparsemap_oracle.c choice by choice (C1..C6 there) so that the
-// active set -- which is path dependent -- comes out identical: every fp64 inner product that
-// feeds a decision is accumulated serially in the oracle's order by ONE lane (lane c owns output
-// c; sums that produce a single scalar are accumulated redundantly by all lanes from LDS
-// broadcasts), there is no FMA contraction (this file is built with -ffp-contract=off; the two
-// explicit fma() calls multiply by exactly 1.0 or 0.0, which makes them plain additions) and
-// division is IEEE.  Parallelism comes from the 64 lanes owning different outputs, from the
-// rank-one updates of the cached inverse KKT matrix, and from one workgroup per sample.
+// The arithmetic follows oracle/sparsemap_oracle.c choice by choice (C1..C8 there) so that the
+// active set -- which is path dependent -- comes out identical: every fp64 sum that feeds a
+// decision adds the same numbers in the oracle's order (C1: the long sums as eight interleaved
+// partial sums combined pairwise, the marginals and residual rows left to right), owned by ONE
+// lane per output (lane c owns output c; sums that produce a single scalar are accumulated
+// redundantly by all lanes from LDS broadcasts), there is no FMA contraction (this file is built
+// with -ffp-contract=off; the two explicit fma() calls multiply by exactly 1.0 or 0.0, which makes
+// them plain additions) and division is IEEE.  Parallelism comes from the 64 lanes owning
+// different outputs, from the eight chains of a blocked sum, from the rank-one updates of the
+// cached inverse KKT matrix, and from one workgroup per sample.
 //
-// The solver is latency bound (a wave walks dependent fp64 additions), so the loops are written
-// as 8-step batches whose LDS operands are fetched one batch ahead (ping-pong registers): a step
-// then costs about one dependent v_add_f64 instead of one LDS round trip.  Every vector that a
-// serial loop reads is kept zero-padded to a multiple of 8 (x + 0.0 == x bit for bit; the sums
+// The solver is latency bound (a lone wave per SIMD walks dependent fp64 additions), so the loops
+// are written as 8-step batches whose LDS operands are fetched one batch ahead (ping-pong
+// registers), and the blocked sums give every step of a batch its own chain.  Every vector that
+// such a loop reads is kept zero-padded to a multiple of 8 (x + 0.0 == x bit for bit; the sums
 // never hold -0.0), and rows of the inverse beyond the live block always hold finite numbers
 // (zero-initialised, later only stale values), so padded steps are exact no-ops.
 //
@@ -113,45 +115,32 @@ __device__ __forceinline__ void ld8(const double* p, double (&v)[8])
     v[4] = t2.x; v[5] = t2.y; v[6] = t3.x; v[7] = t3.y;
 }
 
-// Serial left-to-right sums of NC zero-padded LDS arrays (len8 a multiple of 8, >= 8), all chains
-// advancing together; every lane gets the same bits.
-template <int NC>
-__device__ __forceinline__ void serial_sums(const double* const (&arr)[NC], int len8, double (&acc)[NC])
+// C1 of the oracle: a long sum is accumulated in eight interleaved partial sums (term j goes to
+// partial j mod 8, each partial left to right) that are combined pairwise at the end -- eight
+// independent chains per sum, so a step costs an issue slot, not the latency of a dependent
+// v_add_f64 (a lone wave per SIMD has nothing else to hide it with).
+__device__ __forceinline__ double sum8_get(const double (&p)[8])
 {
-    double a[NC][8], b[NC][8];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { acc[c] = 0.0; ld8(arr[c], a[c]); }
-    int k0 = 0;
-    for (;;) {
-        int kn = k0 + 8 < len8 ? k0 + 8 : len8 - 8;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) ld8(arr[c] + kn, b[c]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += a[c][u];
-        k0 += 8;
-        if (k0 >= len8) break;
-        kn = k0 + 8 < len8 ? k0 + 8 : len8 - 8;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) ld8(arr[c] + kn, a[c]);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += b[c][u];
-        k0 += 8;
-        if (k0 >= len8) break;
-    }
+    return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
 }
 
-// sum_{j < cnt8} col[j*LD] * b[j], serial in j (product rounded, then added); b zero-padded.
+// C1, sums that produce one scalar from a vector spread over the lanes: every lane brings the
+// partial of the terms j = lane (mod 64); the 64 partials are combined by a balanced binary tree
+// over adjacent pairs (quads, half rows, rows by DPP, then (r0 + r1) + (r2 + r3) across the rows --
+// at mirrored lanes a + b and b + a are the same bits), the same bits in every lane.
+__device__ __forceinline__ double wave_sum(double partial)
+{
+    return readlane_f64(group_reduce<64>(partial, OpSum{}), 0);
+}
+
+// sum_{j < cnt8} col[j*LD] * b[j] as a blocked sum (C1; product rounded, then added); b zero-padded.
 template <int LD>
 __device__ __forceinline__ double matvec_col(const double* col, const double* b, int cnt8)
 {
-    double acc = 0.0;
+    double part[8];
     double a0[8], b0[8], a1[8], b1[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a0[u] = col[u * LD];
+    for (int u = 0; u < 8; ++u) { part[u] = 0.0; a0[u] = col[u * LD]; }
     ld8(b, b0);
     int j0 = 0;
     for (;;) {
@@ -160,7 +149,7 @@ __device__ __forceinline__ double matvec_col(const double* col, const double* b,
         for (int u = 0; u < 8; ++u) a1[u] = col[(jn + u) * LD];
         ld8(b + jn, b1);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const double t = a0[u] * b0[u]; acc += t; }
+        for (int u = 0; u < 8; ++u) { const double t = a0[u] * b0[u]; part[u] += t; }
         j0 += 8;
         if (j0 >= cnt8) break;
         jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
@@ -168,89 +157,29 @@ __device__ __forceinline__ double matvec_col(const double* col, const double* b,
         for (int u = 0; u < 8; ++u) a0[u] = col[(jn + u) * LD];
         ld8(b + jn, b0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const double t = a1[u] * b1[u]; acc += t; }
+        for (int u = 0; u < 8; ++u) { const double t = a1[u] * b1[u]; part[u] += t; }
         j0 += 8;
         if (j0 >= cnt8) break;
     }
-    return acc;
-}
-
-// The same for NQ columns at once (lane c, c + 64, ...: the chunks of a matrix-vector product):
-// NQ independent chains advance together, so a step costs an issue slot instead of the latency of
-// a dependent v_add_f64 (a lone wave per SIMD has nothing else to hide it with).  Each chain adds
-// the same numbers in the same order as matvec_col.
-template <int LD, int NQ>
-__device__ __forceinline__ void matvec_cols(const double* const (&col)[NQ], const double* b, int cnt8,
-                                            double (&acc)[NQ])
-{
-    double a0[NQ][8], a1[NQ][8], b0[8], b1[8];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        acc[q] = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a0[q][u] = col[q][u * LD];
-    }
-    ld8(b, b0);
-    int j0 = 0;
-    for (;;) {
-        int jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a1[q][u] = col[q][(jn + u) * LD];
-        ld8(b + jn, b1);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { const double t = a0[q][u] * b0[u]; acc[q] += t; }
-        j0 += 8;
-        if (j0 >= cnt8) break;
-        jn = j0 + 8 < cnt8 ? j0 + 8 : cnt8 - 8;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a0[q][u] = col[q][(jn + u) * LD];
-        ld8(b + jn, b0);
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) { const double t = a1[q][u] * b1[u]; acc[q] += t; }
-        j0 += 8;
-        if (j0 >= cnt8) break;
-    }
+    return sum8_get(part);
 }
 
 // out[q] = sum_{j < cnt8} A[j][c_q] rhs[j] for this lane's columns c_q = lane + 64 q of the chunks
 // that hold an output or padding to clear (q 64 <= cnt8, c_q < NA); columns beyond LD - 1 read the
-// last one (their result is discarded).  Returns the number of chunks computed.
+// last one (their result is discarded).
 template <int LD, int NA>
-__device__ __forceinline__ int matvec_chunks(const double* A, const double* rhs, int cnt8, int lane,
-                                             double (&out)[(NA + 63) / 64])
+__device__ __forceinline__ void matvec_chunks(const double* A, const double* rhs, int cnt8, int lane,
+                                              double (&out)[(NA + 63) / 64])
 {
     constexpr int NQ = (NA + 63) / 64;
-    static_assert(NQ <= 3, "at most three 64-lane chunks (n <= 128)");
-    int nq = cnt8 / 64 + 1;
-    nq = nq < NQ ? nq : NQ;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) out[q] = 0.0;
-    auto colp = [&](int q) { const int c = lane + 64 * q; return A + (c < LD ? c : LD - 1); };
-    if (NQ == 1 || nq == 1) {
-        out[0] = matvec_col<LD>(colp(0), rhs, cnt8);
-    } else if (NQ == 2 || nq == 2) {
-        const double* const col[2] = {colp(0), colp(1)};
-        double acc[2];
-        matvec_cols<LD, 2>(col, rhs, cnt8, acc);
-        out[0] = acc[0];
-        if constexpr (NQ >= 2) out[1] = acc[1];
-    } else {
-        const double* const col[3] = {colp(0), colp(1), colp(2)};
-        double acc[3];
-        matvec_cols<LD, 3>(col, rhs, cnt8, acc);
-        out[0] = acc[0];
-        if constexpr (NQ >= 2) out[1] = acc[1];
-        if constexpr (NQ >= 3) out[2] = acc[2];
+    for (int q = 0; q < NQ; ++q) {
+        out[q] = 0.0;
+        if (q * 64 <= cnt8) {
+            const int c = lane + 64 * q;
+            out[q] = matvec_col<LD>(A + (c < LD ? c : LD - 1), rhs, cnt8);
+        }
     }
-    return nq;
 }
 
 __device__ __forceinline__ double f64_from_hi(int hi)
@@ -346,44 +275,47 @@ struct Sm {
                                              const double (&eta)[NK], int budget, double& value,
                                              double& evalsum) const
     {
-        double* a0 = c0();
         double* a1 = c1();
         double* a2 = c2();
         if (budget <= 0) {
+            // C1: term k goes to partial k mod 64 = this lane, in the order q = 0, 1, ...
+            double pv = 0.0, pe = 0.0;
 #pragma unroll
             for (int q = 0; q < NK; ++q) {
                 const int k = lane + 64 * q;
                 const bool valid = k < n;
                 const bool bit = valid && (on[q] > off[q]);
-                a0[k] = valid ? (bit ? on[q] : off[q]) : 0.0;
-                a1[k] = bit ? eta[q] : 0.0;
+                pv += valid ? (bit ? on[q] : off[q]) : 0.0;
+                pe += bit ? eta[q] : 0.0;
                 put_bits(q, __ballot(bit));
             }
-            wsync();
-            const double* const arr[2] = {a0, a1};
-            double acc[2];
-            serial_sums<2>(arr, n8, acc);
-            value = acc[0];
-            evalsum = acc[1];
-            wsync();
+            value = wave_sum(pv);
+            evalsum = wave_sum(pe);
+            wsync();   // newc
             return;
         }
         // budget factor
         double ev[NK];
         bool sel[NK];
         int num_active = 0;
+        double p_off = 0.0, p_gain = 0.0;   // C1: partials of sum off_k and of the selected gains
 #pragma unroll
         for (int q = 0; q < NK; ++q) {
             const int k = lane + 64 * q;
             const bool valid = k < n;
             ev[q] = on[q] - off[q];
             sel[q] = valid && (ev[q] > 0);
-            a0[k] = valid ? off[q] : 0.0;
-            a1[k] = sel[q] ? ev[q] : 0.0;  // adding 0.0 for the inactive ones changes nothing
-            e()[k] = valid ? ev[q] : -INFINITY;  // padding never outranks anything
+            p_off += valid ? off[q] : 0.0;
+            p_gain += sel[q] ? ev[q] : 0.0;  // adding 0.0 for the inactive ones changes nothing
             num_active += __popcll(__ballot(sel[q]));
         }
         if (uni(num_active > budget)) {
+#pragma unroll
+            for (int q = 0; q < NK; ++q) {
+                const int k = lane + 64 * q;
+                a1[k] = 0.0;                                  // (ranks of valid variables cover 0..n-1)
+                e()[k] = k < n ? ev[q] : -INFINITY;           // padding never outranks anything
+            }
             wsync();
             // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
             const double* ee = e();
@@ -441,20 +373,22 @@ struct Sm {
                 sel[q] = valid && (rank[q] < budget) && !(ev[q] < 0);
                 if (valid) a1[rank[q]] = sel[q] ? ev[q] : 0.0;  // sorted, zero beyond the selection
             }
+            wsync();
+            // the chosen gains are summed in RANK order: rank r goes to partial r mod 64
+            p_gain = 0.0;
+#pragma unroll
+            for (int q = 0; q < NK; ++q) p_gain += a1[lane + 64 * q];
         }
+        double pe = 0.0;
 #pragma unroll
         for (int q = 0; q < NK; ++q) {
-            const int k = lane + 64 * q;
-            a2[k] = sel[q] ? eta[q] : 0.0;
+            pe += sel[q] ? eta[q] : 0.0;
             put_bits(q, __ballot(sel[q]));
         }
-        wsync();
-        const double* const arr[3] = {a0, a1, a2};
-        double acc[3];
-        serial_sums<3>(arr, n8, acc);
-        value = acc[0] + acc[1];
-        evalsum = acc[2];
-        wsync();
+        const double v_off = wave_sum(p_off), v_gain = wave_sum(p_gain);
+        value = v_off + v_gain;
+        evalsum = wave_sum(pe);
+        wsync();   // newc; a1 / e are reused by the next call
     }
 
     // Linear oracle of the binary sequence factor (lvmhelpers/sequence_binary.h:11-38 on
@@ -540,10 +474,11 @@ struct Sm {
             put_bits(q, bits[q]);
         }
         wsync();
-        const double* const arr[1] = {ev};
-        double acc[1];
-        serial_sums<1>(arr, round8(2 * n), acc);
-        evalsum = acc[0];
+        // C1: term j of the interleaved sequence goes to partial j mod 64
+        double pe = 0.0;
+#pragma unroll
+        for (int t = 0; t < 2 * NK; ++t) pe += ev[lane + 64 * t];
+        evalsum = wave_sum(pe);
         wsync();
     }
 };
@@ -708,7 +643,6 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     double* d = S.d();
     double* r = S.r();
     double* t1 = S.t1();
-    double* prod = S.prod();
     uint32_t* cfg = S.cfg();
     uint32_t* newc = S.newc();
 
@@ -784,7 +718,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     // C7: judged / refined are never set when a sample is parked (that happens in an insertion
     // pass, which clears them); the rebuild / re-judgement counts travel in ws_state
     bool judged = false, refined = false;
-    // [tau; z] (+)= invA^T rhs: lane c owns output c, serial in j like the oracle
+    // [tau; z] (+)= invA^T rhs: lane c owns output c, blocked over j like the oracle (C1)
     auto kkt_apply = [&](const double* rhs, bool accumulate) {
         const int cnt8 = round8(m + 1);
         double t0 = 0.0;
@@ -899,12 +833,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         }
         return __any(dup) != 0;
     };
-    // d = invA r (zero beyond m), prod = r .* d; returns s = n - sum_j r_j d_j (serial)
+    // d = invA r (zero beyond m), prod = r .* d; returns s = n - sum_j r_j d_j
     auto insertion_direction = [&]() -> double {
         wsync();
         const int cnt8 = round8(m + 1);
         double mv[(L::NA + 63) / 64];
         matvec_chunks<LD, L::NA>(A, r, cnt8, lane, mv);
+        double prd = 0.0;
 #pragma unroll
         for (int q = 0; q * 64 < L::NA; ++q) {
             const int j = lane + 64 * q;
@@ -912,29 +847,12 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 const double acc = mv[q];
                 const double dj = (j <= m) ? acc : 0.0;
                 d[j] = dj;
-                prod[j] = r[j] * dj;   // r is 0 beyond m
+                prd += r[j] * dj;   // r is 0 beyond m
             }
         }
         wsync();
         SM_T(4);
-        double acc = (double)n;
-        double a[8], b[8];
-        ld8(prod, a);
-        int k0 = 0;
-        for (;;) {
-            int kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
-            ld8(prod + kn, b);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc -= a[u];
-            k0 += 8;
-            if (k0 >= cnt8) break;
-            kn = k0 + 8 < cnt8 ? k0 + 8 : cnt8 - 8;
-            ld8(prod + kn, a);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc -= b[u];
-            k0 += 8;
-            if (k0 >= cnt8) break;
-        }
+        const double acc = (double)n - wave_sum(prd);   // C1: s = n - sum_j r_j d_j, partial j mod 64
         return acc;
     };
     for (; it < max_iter; ++it) {
