@@ -32,6 +32,7 @@ Extra objects on that line:
   sparsemap     batched active-set solver, SURVEY.md 8(d) S5 grid: samples/s, active-set
                 iterations/s, converged / stalled fractions (N > 1: every rank solves 1024 samples
                 at 128 bits = BASELINE.json configs[4] sharded, whole-job rate)
+  sparsemap_sequence  the binary sequence factor (sequence_smap) on the same solver, 2 shapes
   train_steps   one optimisation step of each BASELINE.json model config on synthetic data (N > 1:
                 config 5 with the flat-bucket gradient all-reduce over RCCL); config 2 also in the
                 support-only and hoisted-decoder modes
@@ -385,6 +386,25 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=20, world=1, seed=77)
     return res
 
 
+def sparsemap_seq_bench(native, dev, B, n, sigma, reps=20, seed=77):
+    """The binary sequence factor (sequence_smap) on the same solver: node scores
+    and edge potentials ~ N(0, sigma^2)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(B, n, device=dev, generator=g) * sigma
+    t = torch.randn(B, n - 1, device=dev, generator=g) * sigma
+    init = torch.rand(B, 2 * n, dtype=torch.double,
+                      generator=torch.Generator().manual_seed(42)).to(dev)
+    out = native.sparsemap_seq_fwd(x, t, init, 300)
+    ms = median_ms(lambda: native.sparsemap_seq_fwd(x, t, init, 300), reps, 2)
+    dp = torch.randn(B, n + 1, device=dev, generator=g)
+    bms = median_ms(lambda: native.sparsemap_seq_bwd(dp, out["aset_bits"], out["alen"], out["inv_a"], n), reps, 2)
+    iters = float(out["iters"].double().sum().item())
+    return {"factor": "sequence_binary", "B": B, "positions": n, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
+            "launches": reps, "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
+            "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
+            "converged_frac": float((out["status"] == 0).float().mean().item())}
+
+
 def compaction_bench(native, dev, R, K, sigma):
     """Kernel 2 on the probabilities of a forward pass, every launch through the C ABI on
     preallocated buffers (median of 20): support_count, support_offsets, support_compact, their
@@ -684,6 +704,8 @@ def main():
         out["sparsemap"] = [sparsemap_bench(native, dev, B, n, bud, sg)
                             for (B, n) in ((64, 32), (1024, 128), (8192, 128))
                             for bud in (0, n // 2) for sg in (1.0, 3.0)]
+        out["sparsemap_sequence"] = [sparsemap_seq_bench(native, dev, 64, 32, 1.0),
+                                     sparsemap_seq_bench(native, dev, 1024, 128, 1.0)]
     if _dist_on() and not a.no_sweep:
         # cfg5: batch 8192 over 8 GPUs = 1024 samples per rank at 128 bits; samples sharded, no collective
         out["sparsemap"] = [sparsemap_bench(native, dev, 1024, 128, 0, 1.0, world=world, seed=77 + rank),
