@@ -106,6 +106,21 @@ __device__ __forceinline__ double bcast_f64(double v, int lane)
     return __builtin_bit_cast(double, b);
 }
 
+struct OpMinD { __device__ __forceinline__ double operator()(double a, double b) const { return fmin(a, b); } };
+struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+// Wave-wide lexicographic minimum of (value, index) pairs, one pair per lane (index 0x7fffffff =
+// the lane has no candidate; values are not NaN): two DPP reductions -- the smallest value, then
+// the smallest index among the lanes that hold it -- instead of a six-step butterfly of LDS
+// permutes.  Every lane gets the winner; index 0x7fffffff if no lane had a candidate.
+__device__ __forceinline__ void wave_argmin(double& best, int& best_i)
+{
+    const double v = best_i == 0x7fffffff ? INFINITY : best;
+    const double vmin = readlane_f64(group_reduce<64>(v, OpMinD{}), 0);
+    const int cand = (best_i != 0x7fffffff && v == vmin) ? best_i : 0x7fffffff;
+    best_i = __builtin_amdgcn_readfirstlane(group_reduce<64>(cand, OpMinI{}));
+    best = vmin;
+}
+
 // 8 consecutive doubles from a 16-byte aligned LDS address (4 x ds_read_b128)
 __device__ __forceinline__ void ld8(const double* p, double (&v)[8])
 {
@@ -947,16 +962,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                     const double tq = dist[i] / di;
                     if (best_i == 0x7fffffff || tq < best) { best = tq; best_i = i; }
                 }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const double ob = bcast_f64(best, (lane ^ o));
-                    const int oi = __shfl(best_i, lane ^ o);
-                    if (oi != 0x7fffffff &&
-                        (best_i == 0x7fffffff || ob < best || (ob == best && oi < best_i))) {
-                        best = ob;
-                        best_i = oi;
-                    }
-                }
+                wave_argmin(best, best_i);
                 const int leaving = uni(best_i);
                 if (leaving == 0x7fffffff) { st = SM_SINGULAR; break; }
                 const double theta = uni(best);
@@ -1041,12 +1047,17 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             bool exist = false;
             for (int i = lane; i < m; i += 64) {
                 const double zi = z[i], pi = dist[i];
-                if (zi >= pi) continue;
-                if (zi < 0) exist = true;
-                const double tmp = pi / (pi - zi);
-                if (tmp < best) { best = tmp; best_i = i; }  // ascending i inside a lane
+                if (zi < pi && zi < 0) exist = true;
             }
             exist = __any(exist);
+            if (exist) {   // (the ratios -- an IEEE division each -- only when a constraint blocks)
+                for (int i = lane; i < m; i += 64) {
+                    const double zi = z[i], pi = dist[i];
+                    if (zi >= pi) continue;
+                    const double tmp = pi / (pi - zi);
+                    if (tmp < best) { best = tmp; best_i = i; }  // ascending i inside a lane
+                }
+            }
             if (!exist) {
                 for (int i = lane; i < m; i += 64) dist[i] = z[i];
                 changed = false;
@@ -1054,12 +1065,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 SM_T(8);
             } else {
                 // wave argmin (value, then index)
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    const double ob = bcast_f64(best, (lane ^ o));
-                    const int oi = __shfl(best_i, lane ^ o);
-                    if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
-                }
+                wave_argmin(best, best_i);
                 double alpha = uni(best);
                 const int blocking = uni(best_i);
                 if (alpha > 1.0) alpha = 1.0;
