@@ -163,6 +163,42 @@ static double timeit(F f, int reps = 10)
     return ms / reps * 1e-3;
 }
 
+// persistent waves, software pipelined over 16 U-byte tiles: the loads of the next tile are issued
+// chunk by chunk between the stores of the current one (MODE 0), or all before them (MODE 1)
+template <int U, int MODE, bool REMAP>
+__global__ __launch_bounds__(256) void k_copy_pipe(const float4* __restrict__ a, float4* __restrict__ o, size_t ntiles)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const size_t W = (size_t)gridDim.x * 4;
+    size_t b = blockIdx.x;
+    if (REMAP) { const size_t per = gridDim.x / 8; b = (blockIdx.x % 8) * per + blockIdx.x / 8; }
+    size_t t = b * 4 + (threadIdx.x >> 6);
+    const f4* s4 = reinterpret_cast<const f4*>(a);
+    f4* d4 = reinterpret_cast<f4*>(o);
+    f4 cur[U], nxt[U];
+    if (t >= ntiles) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = __builtin_nontemporal_load(s4 + t * (64 * U) + u * 64 + lane);
+    for (;;) {
+        const size_t tn = t + W;
+        const bool more = tn < ntiles;
+        if (MODE == 1 && more) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u] = __builtin_nontemporal_load(s4 + tn * (64 * U) + u * 64 + lane);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (MODE == 0 && more) nxt[u] = __builtin_nontemporal_load(s4 + tn * (64 * U) + u * 64 + lane);
+            __builtin_nontemporal_store(cur[u], d4 + t * (64 * U) + u * 64 + lane);
+        }
+        if (!more) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        t = tn;
+    }
+}
+
 int main(int argc, char** argv)
 {
     size_t bytes = (size_t)16 << 30;  // per tensor
@@ -172,6 +208,19 @@ int main(int argc, char** argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
     double t;
+    if (argc > 4) {
+        const size_t ntiles = n / (64 * 16);
+#define PP(MODE, RM, G) t = timeit([&] { k_copy_pipe<16, MODE, RM><<<G, 256>>>(a, o, ntiles); }); \
+    printf("copy pipelined U=16 mode=%d remap=%d grid=%d: %.2f TB/s\n", MODE, (int)RM, G, 2.0 * bytes / t / 1e12);
+        PP(0, false, 1024) PP(0, false, 2048) PP(0, true, 1024) PP(0, true, 2048) PP(1, false, 1024) PP(1, true, 1024) PP(0, false, 512) PP(0, false, 4096) PP(0, true, 4096) PP(1, true, 2048)
+        t = timeit([&] { k_copy_tile_nt<16, true, true, 256><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+        printf("copy tile U=16 nt-both (one tile per wave): %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+        t = timeit([&] { k_copy_tile_xcd<16, true, 256, 0><<<(unsigned)(n / (16 * 256)), 256>>>(a, o, n); });
+        printf("copy tile U=16 nt-both xcd-remap: %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+        t = timeit([&] { k_copy_tile_nt<1, true, true, 256><<<(unsigned)(n / (1 * 256)), 256>>>(a, o, n); });
+        printf("copy tile U=1 nt-both: %.2f TB/s\n", 2.0 * bytes / t / 1e12);
+        return 0;
+    }
     if (argc > 3) {
 #define FL(U, NT, BS, RM) t = timeit([&] { k_fill_tile<U, NT, BS, RM><<<(unsigned)(n / ((size_t)U * BS)), BS>>>(o, n); }); \
     printf("fill tile U=%d nt=%d BS=%d remap=%d: %.2f TB/s\n", U, (int)NT, BS, (int)RM, 1.0 * bytes / t / 1e12);
