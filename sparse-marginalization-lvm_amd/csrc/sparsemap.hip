@@ -325,21 +325,38 @@ struct Sm {
             num_active += __popcll(__ballot(sel[q]));
         }
         if (uni(num_active > budget)) {
+            // More positive gains than the budget admits: the `budget` largest are kept (sort of
+            // (-e_i, i) ascending, budget.h:49-76).  Only the positives compete -- every one of
+            // them sorts before every e_i <= 0 -- so they are compacted first (in index order:
+            // comparing slots is comparing indices) and ranked among themselves: the pair loop
+            // runs over num_active entries instead of n.
+            const int P = uni(num_active), P8 = round8(P);
+            int slot[NK];
+            {
+                int base = 0;
+#pragma unroll
+                for (int q = 0; q < NK; ++q) {
+                    const unsigned long long mk = __ballot(sel[q]);
+                    slot[q] = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                    base += __popcll(mk);
+                }
+            }
+            double* ee = e();
 #pragma unroll
             for (int q = 0; q < NK; ++q) {
                 const int k = lane + 64 * q;
-                a1[k] = 0.0;                                  // (ranks of valid variables cover 0..n-1)
-                e()[k] = k < n ? ev[q] : -INFINITY;           // padding never outranks anything
+                a1[k] = 0.0;                                  // (ranks cover 0..P-1, the rest stays zero)
+                if (sel[q]) ee[slot[q]] = ev[q];
+                if (k >= P && k < P8) ee[k] = -INFINITY;      // padding never outranks anything
             }
             wsync();
-            // rank in the order of sort((-e_i, i)) ascending: e descending, ties by smaller index
-            const double* ee = e();
             int rank[NK];
 #pragma unroll
             for (int q = 0; q < NK; ++q) rank[q] = 0;
             // first with "greater" alone (one compare + one add-with-carry per pair): exact unless
             // two gains are equal, in which case two variables get the same rank
-            for (int j0 = 0; j0 < n8; j0 += 8) {
+            for (int j0 = 0; j0 < P8; j0 += 8) {
                 double ej[8];
                 ld8(ee + j0, ej);
 #pragma unroll
@@ -348,45 +365,38 @@ struct Sm {
                     for (int q = 0; q < NK; ++q) rank[q] += (ej[u] > ev[q]) ? 1 : 0;
                 }
             }
-            // ranks of valid variables are distinct iff there was no tie: every variable claims its
-            // slot and looks who holds it afterwards
+            // ranks of the positives are distinct iff there was no tie: every one claims its slot
+            // and looks who holds it afterwards
             int* claim = reinterpret_cast<int*>(a2);
             bool clash = false;
 #pragma unroll
-            for (int q = 0; q < NK; ++q) {
-                const int k = lane + 64 * q;
-                if (k < n) claim[rank[q]] = k;
-            }
+            for (int q = 0; q < NK; ++q)
+                if (sel[q]) claim[rank[q]] = slot[q];
             wsync();
 #pragma unroll
-            for (int q = 0; q < NK; ++q) {
-                const int k = lane + 64 * q;
-                if (k < n) clash = clash || (claim[rank[q]] != k);
-            }
+            for (int q = 0; q < NK; ++q)
+                if (sel[q]) clash = clash || (claim[rank[q]] != slot[q]);
             wsync();
             if (__any(clash)) {   // rare: the full rule with the index tie-break
 #pragma unroll
                 for (int q = 0; q < NK; ++q) rank[q] = 0;
-                for (int j0 = 0; j0 < n8; j0 += 8) {
+                for (int j0 = 0; j0 < P8; j0 += 8) {
                     double ej[8];
                     ld8(ee + j0, ej);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int j = j0 + u;
 #pragma unroll
-                        for (int q = 0; q < NK; ++q) {
-                            const int k = lane + 64 * q;
-                            rank[q] += ((ej[u] > ev[q]) || (ej[u] == ev[q] && j < k)) ? 1 : 0;
-                        }
+                        for (int q = 0; q < NK; ++q)
+                            rank[q] += ((ej[u] > ev[q]) || (ej[u] == ev[q] && j < slot[q])) ? 1 : 0;
                     }
                 }
             }
 #pragma unroll
             for (int q = 0; q < NK; ++q) {
-                const int k = lane + 64 * q;
-                const bool valid = k < n;
-                sel[q] = valid && (rank[q] < budget) && !(ev[q] < 0);
-                if (valid) a1[rank[q]] = sel[q] ? ev[q] : 0.0;  // sorted, zero beyond the selection
+                const bool pos = sel[q];
+                sel[q] = pos && (rank[q] < budget);
+                if (pos) a1[rank[q]] = sel[q] ? ev[q] : 0.0;  // sorted, zero beyond the selection
             }
             wsync();
             // the chosen gains are summed in RANK order: rank r goes to partial r mod 64
