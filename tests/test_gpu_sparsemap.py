@@ -244,3 +244,21 @@ def test_sequence_factor_swaps_and_tiers(dev, oracle_mod):
     mu = torch.einsum("bc,bcn->bn", out0["p"].double(), bits).cpu().numpy()
     mu_ref = np.clip((x.astype(np.float64) + 1) / 2, 0, 1)
     assert np.abs(mu - mu_ref)[ok].max() <= 1e-6
+
+
+@pytest.mark.parametrize("n", [4, 6, 9, 12, 16, 24])
+def test_sequence_factor_many_swaps(dev, oracle_mod, n):
+    """Short chains are where singular insertions (C8 swaps) are frequent: 2048 of them per length,
+    a third with integer potentials, a few iteration limits; everything identical to the oracle."""
+    from lvmhelpers import _native
+    B = 2048
+    x, t, init = _seq_inputs(B, n, 1.5, 7 * n)
+    x[::3], t[::3] = np.round(x[::3]), np.round(t[::3])
+    for mi in (300, 5):
+        ref = oracle_mod.sparsemap_seq_fwd(x, t, init, max_iter=mi)
+        out = _native.sparsemap_seq_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev),
+                                        torch.from_numpy(init).to(dev), mi)
+        for key in ("status", "iters", "alen", "p"):
+            assert np.array_equal(out[key].cpu().numpy(), ref[key]), (key, mi)
+        assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    assert (ref["iters"] == 5).any()
