@@ -484,7 +484,7 @@ def train_steps_bench(dev, world, rank):
         sup = out["log"].get("support")
         return {"ms_per_step": ms, "samples_per_s": B * world / (ms * 1e-3), "batch_per_gpu": B,
                 "mean_support": float(torch.as_tensor(sup, dtype=torch.float32).mean()) if sup is not None else None,
-                "loss": float(out["loss"])}
+                "loss": float(out["loss"].detach())}
 
     res = {}
     if not _dist_on():
