@@ -146,6 +146,17 @@ def test_marginals_closed_form_full_size(dev, oracle_mod, sigma, budget):
         assert float(err[ok].max()) <= 1e-6
     else:
         assert bool((bits.sum(-1)[out["p"] > 0] <= budget).all())
+        # the marginals are the projection of (x+1)/2 onto {0 <= mu <= 1, sum mu <= budget}
+        # (bisection on the multiplier, vectorised over the batch)
+        a = (x.double() + 1) / 2
+        lo, hi = torch.zeros(B, 1, dtype=torch.double, device=dev), a.max(-1, keepdim=True)[0].clamp(min=0)
+        for _ in range(100):
+            mid = (lo + hi) / 2
+            over = (a - mid).clamp(0, 1).sum(-1, keepdim=True) > budget
+            lo, hi = torch.where(over, mid, lo), torch.where(over, hi, mid)
+        free = a.clamp(0, 1).sum(-1, keepdim=True) <= budget
+        mu_ref = torch.where(free, a.clamp(0, 1), (a - hi).clamp(0, 1))
+        assert float((mu - mu_ref).abs().max(dim=-1)[0][ok].max()) <= 1e-6
     # the first 96 samples against the oracle: identical, and accurate to 1e-9 in fp64 there
     nb = 96
     ref = oracle_mod.sparsemap_fwd(x[:nb].cpu().numpy(), init[:nb].cpu().numpy(), budget, 300)
