@@ -207,7 +207,7 @@ def timed_sparsemax(native, x, dy, steps, warmup, world, dev):
     p = torch.empty_like(x)
     dx = torch.empty_like(x)
     supp = torch.empty(R, dtype=torch.int32, device=dev)
-    cap = native.SUPPORT_COLS_CAP
+    cap = native.support_cols_cap(K)
     cols = torch.empty((R, cap), dtype=torch.int32, device=dev)
     L = native.lib()
     import ctypes

@@ -59,7 +59,7 @@ int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_siz
  * columns of the non-zeros of every row, the backward gathers dy at those columns and zero-fills dx
  * (no read of p, no streaming read of dy: the backward of sparsemax is O(support) reads + one dense
  * write).  What entmax keeps on the autograd ctx is (supp_size, p); this keeps (supp_size, lists).
- *   support_cols [R, cap] int32, 1 <= cap <= 64: columns with p > 0 in no particular order, -1 in
+ *   support_cols [R, cap] int32, 1 <= cap <= 64 (<= 128 for K > 4096): columns with p > 0 in no particular order, -1 in
  *   unused slots; first entry -2 = no list for this row (more than cap non-zeros, or a row whose
  *   threshold search could not run on a candidate list: more than 256 elements within 1 of the row
  *   maximum after the bound has been raised; for K > 4096 more than 64 of them in one wave's 64 E

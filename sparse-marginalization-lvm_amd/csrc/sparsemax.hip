@@ -477,6 +477,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
 // list for this row" (more than cap non-zeros, or a row wider than one wave's tile) and sends the
 // backward to the p-based path.
 constexpr int kColsNone = -1, kColsOverflow = -2, kColsMask = -3, kColsMaxCap = 64;
+// rows wider than a wave's tile (K > 4096: 16 KB and more per row) may carry longer lists: the
+// segment backward reads two slots per lane
+constexpr int kColsMaxCapWide = 128;
 // kColsMask in slot 0: no list, but the row's non-zero pattern is in the support-mask buffer (one
 // 64-bit word per lane of the <64, E> tile, bit e = register e: a layout private to this file and
 // only written / read by the 16-byte-layout kernels with E >= 32, i.e. 1024 < K <= 4096).  The
@@ -1616,6 +1619,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segmen
     const int64_t row = wid / nseg;
     const int seg = (int)(wid - row * nseg);
     const int c = lane < cap ? cols[row * cap + lane] : kColsNone;
+    const int c2 = lane + 64 < cap ? cols[row * cap + lane + 64] : kColsNone;   // cap <= kColsMaxCapWide
     if (__builtin_amdgcn_readfirstlane(c) == kColsOverflow) return;
     float* dxrow = dx + row * K;
     {
@@ -1632,12 +1636,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segmen
         }
     }
     const float v = c >= 0 ? dy[row * K + c] : 0.0f;
+    const float v2 = c2 >= 0 ? dy[row * K + c2] : 0.0f;
     WaveRed<64> red;
-    const double acc = red.sum((double)v);
+    // (fp64 sum of <= 128 fp32 values by the wave's tree: differs from the streaming kernel's
+    // column order by fp64 rounding only, far below the fp32 result)
+    const double acc = red.sum((double)v + (double)v2);
     const float mean = (float)acc / (float)supp[row];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (c >= 0 && (c >> 12) == seg) dxrow[c] = v - mean;
+    if (c2 >= 0 && (c2 >> 12) == seg) dxrow[c2] = v2 - mean;
 }
 
 template <int NW, int E, bool VEC, bool FULL>
@@ -2362,7 +2370,7 @@ extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_
                                         void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
-    if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
+    if (support_cols && (cap < 1 || cap > (K > 4096 ? kColsMaxCapWide : kColsMaxCap))) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
     FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
@@ -2392,7 +2400,7 @@ extern "C" int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_
                                         void* stream)
 {
     if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
-    if (support_cols && (cap < 1 || cap > kColsMaxCap)) return SMLVM_ERR_INVALID;
+    if (support_cols && (cap < 1 || cap > (K > 4096 ? kColsMaxCapWide : kColsMaxCap))) return SMLVM_ERR_INVALID;
     if (R == 0) return SMLVM_OK;
     if (!dy || !p || !supp_size || !dx) return SMLVM_ERR_INVALID;
     BwdArgs a{dy, p, supp_size, dx, R, K, (hipStream_t)stream,

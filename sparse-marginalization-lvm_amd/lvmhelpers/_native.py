@@ -93,12 +93,20 @@ _f32 = ctypes.c_float
 
 # ----------------------------------------------------------------------------------- sparsemax
 SUPPORT_COLS_CAP = 32   # slots per row of the forward's support list (128 B per row)
+SUPPORT_COLS_CAP_WIDE = 128   # rows wider than a wave's tile (K > 4096: 16 KB and more per row)
+
+
+def support_cols_cap(K):
+    """List capacity the forward is asked for: a list stops paying near 45 entries at K <= 4096
+    (one 64-byte gather and one scattered store per entry against a 16 KB row), far later for the
+    segment backward of wider rows."""
+    return SUPPORT_COLS_CAP if K <= 4096 else SUPPORT_COLS_CAP_WIDE
 
 
 def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False,
                   want_mask=False):
     """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None).
-    want_cols=True appends the support lists [R, SUPPORT_COLS_CAP] i32 for sparsemax_bwd_cols;
+    want_cols=True appends the support lists [R, support_cols_cap(K)] i32 for sparsemax_bwd_cols;
     want_mask=True (with want_cols) appends the support-mask buffer as well (None when the shape
     has none: only 1024 < K <= 4096), which lets the backward skip p for rows with more non-zeros
     than a list holds."""
@@ -114,7 +122,8 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
             _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
                                              _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
         return p, supp, nnz, tau, ent
-    cols = torch.empty((R, SUPPORT_COLS_CAP), dtype=torch.int32, device=x.device)
+    cap = support_cols_cap(K)
+    cols = torch.empty((R, cap), dtype=torch.int32, device=x.device)
     mask = None
     if want_mask:
         nbytes = lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K))
@@ -123,7 +132,7 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
             mask = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
-                                              _p(cols), _i32(SUPPORT_COLS_CAP), _p(mask), _i64(R),
+                                              _p(cols), _i32(cap), _p(mask), _i64(R),
                                               _i32(K), _stream()), "smlvm_sparsemax_fwd_cols")
     if want_mask:
         return p, supp, nnz, tau, ent, cols, mask
@@ -234,6 +243,8 @@ def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True,
         if support_cols.dim() != 2 or support_cols.shape[0] != R:
             raise ValueError("support_cols must be [R, cap]")
         cap = support_cols.shape[1]
+        if cap > 64:   # the list-fed compaction kernels take caps up to 64: scan p instead
+            support_cols, cap = None, 0
     if nnz is None:
         if support_cols is None:
             nnz = support_count(p)

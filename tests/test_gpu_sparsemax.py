@@ -677,3 +677,44 @@ def test_fuzz_rows_from_the_algorithm_model(dev, oracle_mod, K):
     for m in (mask, None):
         dx = _native.sparsemax_bwd_cols(dyt, cols, p, supp, m)
         assert np.all(np.abs(dx.cpu().numpy() - dx_ref) <= 1e-6 * scale)
+
+
+@pytest.mark.parametrize("K,sigma", [(8192, 0.08), (16384, 0.07), (65536, 0.05), (65536, 0.035), (70000, 0.05)])
+def test_wide_rows_carry_lists_of_up_to_128_columns(dev, oracle_mod, K, sigma):
+    """Rows wider than a wave's tile (K > 4096) get 128-slot lists (lvmhelpers._native.
+    support_cols_cap): supports of 33 ... 128 non-zeros, which used to send the backward to the
+    p-based gather, are listed and the segment backward reads two slots per lane."""
+    from lvmhelpers import _native
+    R = 96
+    rng = np.random.default_rng(K + int(1000 * sigma))
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    p_ref, s_ref, _, _ = oracle_mod.sparsemax_fwd(x)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    p, supp, _, _, _, cols = _native.sparsemax_fwd(torch.from_numpy(x).to(dev), want_cols=True)
+    assert cols.shape[1] == 128 == _native.support_cols_cap(K)
+    assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(supp.cpu().numpy(), s_ref)
+    c = cols.cpu().numpy()
+    nnz = (p_ref > 0).sum(1)
+    assert ((nnz > 32) & (nnz <= 128)).any()
+    long_listed = 0
+    for r in range(R):
+        if c[r, 0] >= 0:
+            nz = np.flatnonzero(p_ref[r] > 0)
+            assert nz.size <= 128 and sorted(c[r, :nz.size].tolist()) == nz.tolist()
+            assert np.all(c[r, nz.size:] == -1)
+            long_listed += nz.size > 64
+        else:
+            assert c[r, 0] == -2
+    assert long_listed > 0 or (nnz <= 64).all() or (nnz > 128).all()
+    dx = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp).cpu().numpy()
+    scale = np.maximum(np.abs(dy).max(axis=1, keepdims=True), 1e-30)
+    assert np.all(np.abs(dx - dx_ref) <= 1e-6 * scale)
+    # the C ABI refuses longer lists, and 128 for rows of one wave's tile
+    import ctypes
+    L = _native.lib()
+    one = ctypes.c_void_p(p.data_ptr())
+    assert L.smlvm_sparsemax_fwd_cols(one, one, one, None, None, None, one, ctypes.c_int32(129), None,
+                                      ctypes.c_int64(1), ctypes.c_int32(K), None) == -1
+    assert L.smlvm_sparsemax_fwd_cols(one, one, one, None, None, None, one, ctypes.c_int32(128), None,
+                                      ctypes.c_int64(1), ctypes.c_int32(4096), None) == -1

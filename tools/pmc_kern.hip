@@ -100,7 +100,7 @@ int main(int argc, char** argv)
     typedef int (*wlr_t)(const float*, const float*, const int64_t*, float*, float*, float, int64_t, int64_t, void*, size_t, void*);
     auto fwdc = sym<fwd_cols_t>(h, "smlvm_sparsemax_fwd_cols");
     auto bwdc = sym<bwd_cols_t>(h, "smlvm_sparsemax_bwd_cols");
-    const int cap = 32;
+    const int cap = K > 4096 ? 128 : 32;   // as lvmhelpers._native.support_cols_cap
     const size_t n = (size_t)R * K;
     float *x, *p; int32_t *supp, *nnz, *cols; uint32_t* mask = nullptr;
     CK(hipMalloc(&x, n * 4)); CK(hipMalloc(&p, n * 4)); CK(hipMalloc(&supp, R * 4)); CK(hipMalloc(&nnz, R * 4));
