@@ -227,13 +227,34 @@ def support_offsets(nnz):
     return off
 
 
-def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None):
+def support_row_offsets(p, nnz=None, support_cols=None):
+    """row_offsets [R+1] int64 of the compaction of p (count + exclusive scan, no host sync)."""
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    if support_cols is not None and support_cols.shape[1] > 64:
+        support_cols = None
+    if nnz is None:
+        if support_cols is None:
+            nnz = support_count(p)
+        else:
+            support_cols = _need_gpu(support_cols, torch.int32, "support_cols")
+            nnz = torch.empty(R, dtype=torch.int32, device=p.device)
+            with torch.cuda.device(p.device):
+                _check(lib().smlvm_support_count_cols(_p(p), _p(support_cols), _i32(support_cols.shape[1]),
+                                                      _p(nnz), _i64(R), _i32(K), _stream()),
+                       "smlvm_support_count_cols")
+    return support_offsets(nnz)
+
+
+def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None,
+                    row_offsets=None, total=None):
     """Row-major (rows, cols, vals) lists of the positive entries of p [R,K] plus row_offsets.
 
     support_cols: the forward's support lists for this very p (`sparsemax_fwd(..., want_cols=True)`,
     or `functional.support_cols_of(p)`): rows that have a list are counted and compacted from it
     instead of from their K probabilities; the output is the same.
-    One host sync (reading N = row_offsets[R]) to size the outputs.
+    One host sync (reading N = row_offsets[R]) to size the outputs -- none when the caller has the
+    offsets already (`row_offsets` from support_row_offsets and `total` = N read on its side).
     """
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
@@ -245,17 +266,12 @@ def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True,
         cap = support_cols.shape[1]
         if cap > 64:   # the list-fed compaction kernels take caps up to 64: scan p instead
             support_cols, cap = None, 0
-    if nnz is None:
-        if support_cols is None:
-            nnz = support_count(p)
-        else:
-            nnz = torch.empty(R, dtype=torch.int32, device=p.device)
-            with torch.cuda.device(p.device):
-                _check(lib().smlvm_support_count_cols(_p(p), _p(support_cols), _i32(cap), _p(nnz),
-                                                      _i64(R), _i32(K), _stream()),
-                       "smlvm_support_count_cols")
-    off = support_offsets(nnz)
-    N = int(off[R].item())
+    if row_offsets is not None:
+        off = _need_gpu(row_offsets, torch.int64, "row_offsets")
+        N = int(total) if total is not None else int(off[R].item())
+    else:
+        off = support_row_offsets(p, nnz, support_cols)
+        N = int(off[R].item())
     dev = p.device
     rows = torch.empty(N, dtype=torch.int32, device=dev) if want_rows else None
     cols = torch.empty(N, dtype=torch.int32, device=dev) if want_cols else None

@@ -6,6 +6,7 @@ where: k-best enumeration, sparsemax, support compaction, bit unpacking, the bat
 solver and the weighted loss reduction are gfx950 kernels; encoder/decoder networks and the user
 loss stay PyTorch-ROCm ops.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -144,15 +145,24 @@ class SparseMAPWrapper(nn.Module):
         p, aset_bits, alen, _, _ = F_.sparsemap_batched(
             scores, init_scores, self.budget, self.max_iter)
 
-        off, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, support_cols=F_.support_cols_of(p))
-        support = (off[1:] - off[:-1]).tolist()
+        # one read-back per step: the row offsets.  N, `support` and `idxs` (row b repeated
+        # support[b] times: the compaction is in row-major order) follow from them on the host,
+        # while the compaction itself runs on the device.
+        lists = F_.support_cols_of(p)
+        off = _native.support_row_offsets(p.detach(), support_cols=lists)
+        off_h = off.cpu().numpy()
+        counts = np.diff(off_h)
+        support = counts.tolist()
         assert min(support) > 0
+        idxs = np.repeat(np.arange(batch_size), counts).tolist()
+        _, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, support_cols=lists,
+                                                   row_offsets=off, total=int(off_h[-1]))
         rows_l = rows.long()
         sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
         distr = p[rows_l, cols.long()]
         entropy_distr = _support_entropy(distr)
         self._idx_tensor = rows_l
-        return sample, distr, entropy_distr / batch_size, rows_l.tolist(), support
+        return sample, distr, entropy_distr / batch_size, idxs, support
 
 
 class SparseMAPMarg(torch.nn.Module):
