@@ -3,11 +3,15 @@ functions ``SparseMAP`` / ``BernSparseMAP`` / ``BudgetSparseMAP`` (sparsemap.py:
 ``SequenceSparseMAP`` / ``SequenceBinarySparseMAP`` (sparsemap.py:47-87,130-148) and the entry points
 ``bernoulli_smap`` / ``budget_smap`` / ``sequence_smap`` (sparsemap.py:151-160).
 
-As in the reference, a function call builds one factor object (``PFactorBernoulli`` /
-``PFactorBudget``), keeps it on the autograd ``ctx`` (``ctx.f``) and the backward asks that factor
-for the Jacobian-vector product; here the factor is a batch of one sample on the GPU solver and
-its state never leaves the device.  ``structmarg.SparseMAPWrapper`` does not go through these: it
-solves the whole batch in one launch (``functional.sparsemap_batched``).
+As in the reference, a call builds one factor object (``PFactorBernoulli`` / ``PFactorBudget`` /
+``PFactorSequenceBinary``), keeps it on the autograd ``ctx`` (``ctx.f``) and the backward asks that
+factor for the Jacobian-vector product; here the factor is a batch of one sample on the GPU solver
+and its state never leaves the device.  ``structmarg.SparseMAPWrapper`` does not go through these:
+it solves the whole batch in one launch (``functional.sparsemap_batched``).
+
+All five classes share one piece of plumbing (``_solve`` / ``_pull_back`` below); what differs is
+the factor they build and how many potential tensors they take (scores, or scores + edge
+potentials).
 """
 import torch
 
@@ -16,21 +20,30 @@ from .pbudget import PFactorBudget
 from .psequence import PFactorSequenceBinary
 
 
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _solve(cls, ctx, potentials):
+    """Build the factor, draw the init scores like the reference does -- torch.rand(2n,
+    dtype=double) from the global CPU generator, sparsemap.py:25-27,66-69 -- and solve on the GPU."""
+    x = potentials[0]
+    if x.dim() != 1:
+        raise ValueError("expected a 1-D score vector")
+    ctx.n = x.shape[0]
+    ctx.f = cls.make_factor(ctx)
+    init = torch.rand(2 * ctx.n, dtype=torch.double) if ctx.init else None
+    p, aset = ctx.f._solve_device(*[_f32(t) for t in potentials], init, ctx.max_iter)
+    ctx.mark_non_differentiable(aset)
+    return p, aset
+
+
 class SparseMAP(torch.autograd.Function):
-    """Shared plumbing of the per-sample functions (reference: sparsemap.py:10-44)."""
+    """Plumbing of the bit-vector functions (reference: sparsemap.py:10-44)."""
 
     @classmethod
     def run_sparsemap(cls, ctx, x):
-        if x.dim() != 1:
-            raise ValueError("expected a 1-D score vector")
-        ctx.n = x.shape[0]
-        ctx.f = cls.make_factor(ctx)
-        # same draw as the reference: torch.rand(2n, dtype=double) from the global CPU generator,
-        # handed to init_active_set_from_scores (sparsemap.py:25-27)
-        init = torch.rand(2 * ctx.n, dtype=torch.double) if ctx.init else None
-        p, aset = ctx.f._solve_device(x.detach().to(torch.float32).contiguous(), init, ctx.max_iter)
-        ctx.mark_non_differentiable(aset)
-        return p, aset
+        return _solve(cls, ctx, (x,))
 
     @classmethod
     def jv(cls, ctx, dp):
@@ -38,25 +51,18 @@ class SparseMAP(torch.autograd.Function):
 
 
 class SequenceSparseMAP(torch.autograd.Function):
-    """Plumbing of the sequence factors (reference: sparsemap.py:47-87)."""
+    """Plumbing of the sequence functions (reference: sparsemap.py:47-87): node scores x [n] and
+    additional (edge) potentials t [n-1]; the Jacobian-vector product has both parts."""
 
     @classmethod
     def run_sparsemap(cls, ctx, x, t):
-        if x.dim() != 1 or t.dim() != 1 or t.shape[0] != x.shape[0] - 1:
+        if t.dim() != 1 or x.dim() != 1 or t.shape[0] != x.shape[0] - 1:
             raise ValueError("expected x [n] and t [n-1]")
-        ctx.n = x.shape[0]
-        ctx.f = cls.make_factor(ctx)
-        # torch.rand(2n, dtype=double) from the global CPU generator; the additional potentials of
-        # the init call are zeros (sparsemap.py:66-69)
-        init = torch.rand(2 * ctx.n, dtype=torch.double) if ctx.init else None
-        p, aset = ctx.f._solve_device(x.detach().to(torch.float32).contiguous(),
-                                      t.detach().to(torch.float32).contiguous(), init, ctx.max_iter)
-        ctx.mark_non_differentiable(aset)
-        return p, aset
+        return _solve(cls, ctx, (x, t))
 
     @classmethod
     def jv(cls, ctx, dp):
-        return ctx.f._jacobian_vec_device(dp.contiguous())
+        return ctx.f._jacobian_vec_device(dp.contiguous())   # (d eta_u[:n], d eta_v)
 
 
 class BernSparseMAP(SparseMAP):
@@ -64,14 +70,13 @@ class BernSparseMAP(SparseMAP):
 
     @classmethod
     def make_factor(cls, ctx):
-        f = PFactorBernoulli()
-        f.initialize(ctx.n)
-        return f
+        factor = PFactorBernoulli()
+        factor.initialize(ctx.n)
+        return factor
 
     @classmethod
     def forward(cls, ctx, x, max_iter, init):
-        ctx.max_iter = max_iter
-        ctx.init = init
+        ctx.max_iter, ctx.init = max_iter, init
         return cls.run_sparsemap(ctx, x)
 
     @classmethod
@@ -84,15 +89,13 @@ class BudgetSparseMAP(SparseMAP):
 
     @classmethod
     def make_factor(cls, ctx):
-        f = PFactorBudget()
-        f.initialize(ctx.n, ctx.budget)
-        return f
+        factor = PFactorBudget()
+        factor.initialize(ctx.n, ctx.budget)
+        return factor
 
     @classmethod
     def forward(cls, ctx, x, budget, max_iter, init):
-        ctx.init = init
-        ctx.max_iter = max_iter
-        ctx.budget = budget
+        ctx.budget, ctx.max_iter, ctx.init = budget, max_iter, init
         return cls.run_sparsemap(ctx, x)
 
     @classmethod
@@ -105,20 +108,18 @@ class SequenceBinarySparseMAP(SequenceSparseMAP):
 
     @classmethod
     def make_factor(cls, ctx):
-        f = PFactorSequenceBinary()
-        f.initialize(ctx.n)
-        return f
+        factor = PFactorSequenceBinary()
+        factor.initialize(ctx.n)
+        return factor
 
     @classmethod
     def forward(cls, ctx, x, t, max_iter, init):
-        ctx.init = init
-        ctx.max_iter = max_iter
+        ctx.max_iter, ctx.init = max_iter, init
         return cls.run_sparsemap(ctx, x, t)
 
     @classmethod
     def backward(cls, ctx, dp, daset):
-        d_eta_u, d_eta_v = cls.jv(ctx, dp)
-        return d_eta_u, d_eta_v, None, None
+        return (*cls.jv(ctx, dp), None, None)
 
 
 def bernoulli_smap(x, max_iter=100, init=True):
