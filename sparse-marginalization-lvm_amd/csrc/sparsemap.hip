@@ -29,6 +29,7 @@
 #include "common.hpp"
 
 #include <atomic>
+#include <type_traits>
 
 #include <math.h>
 
@@ -444,7 +445,10 @@ struct Sm {
         unsigned long long f0[NK], f1[NK];
 #pragma unroll
         for (int q = 0; q < NK; ++q) { f0[q] = 0ull; f1[q] = 0ull; }
-        for (int i0 = 0; i0 < n8; i0 += 8) {
+        // eight positions; TAIL: the batch that holds position n - 1 and padding (selects keep the
+        // padded steps from moving the values; full batches do without them)
+        auto batch = [&](int i0, auto tail) {
+            constexpr bool TAIL = decltype(tail)::value;
             double o[8], f[8], t[8];
             ld8(a0 + i0, o);
             ld8(a1 + i0, f);
@@ -459,15 +463,25 @@ struct Sm {
                 const bool b1 = (__ballot(c11 > c01) & 1ull) != 0ull;
                 const double best1 = b1 ? c11 : c01;
                 const double nv0 = best0 + f[u], nv1 = best1 + o[u];
-                const bool live = i0 + u < n;
-                v0 = live ? nv0 : v0;
-                v1 = live ? nv1 : v1;
+                if constexpr (TAIL) {
+                    const bool live = i0 + u < n;
+                    v0 = live ? nv0 : v0;
+                    v1 = live ? nv1 : v1;
+                } else {
+                    v0 = nv0;
+                    v1 = nv1;
+                }
                 m0 |= (unsigned long long)b0 << u;
                 m1 |= (unsigned long long)b1 << u;
             }
 #pragma unroll
             for (int q = 0; q < NK; ++q)
                 if ((i0 >> 6) == q) { f0[q] |= m0 << (i0 & 63); f1[q] |= m1 << (i0 & 63); }
+        };
+        {
+            int i0 = 0;
+            for (; i0 + 8 <= n; i0 += 8) batch(i0, std::false_type{});
+            if (i0 < n) batch(i0, std::true_type{});
         }
         const double e0 = v0 + 0.0, e1 = v1 + 0.0;
         bool state = (__ballot(e1 > e0) & 1ull) != 0ull;
