@@ -169,7 +169,8 @@ static double maximize(const double* on, const double* off, int n, int budget, u
 /* Linear oracle of the binary sequence factor (lvmhelpers/sequence_binary.h:11-38 on
  * sequence.h:66-139): Viterbi over n positions with two states; node scores on[k] (state 1) /
  * off[k] (state 0), edge score t[k-1] for the transition (1 -> 1) into position k, 0 for every
- * other edge (start and stop included).  Ties as upstream: the first state of the scan (0) wins
+ * other edge (start and stop included; a zero edge score is not added: x + 0.0 only differs from x
+ * in the sign of a zero).  Ties as upstream: the first state of the scan (0) wins
  * unless the other is strictly better.  Sums in the order of the recursion. */
 static double maximize_seq(const double* on, const double* off, const double* t, int n, uint32_t* cfg,
                            unsigned char* from0, unsigned char* from1)
@@ -178,10 +179,10 @@ static double maximize_seq(const double* on, const double* off, const double* t,
     memset(cfg, 0, sizeof(uint32_t) * (size_t)W);
     double v0 = off[0] + 0.0, v1 = on[0] + 0.0;
     for (int i = 1; i < n; ++i) {
-        const double c00 = v0 + 0.0, c10 = v1 + 0.0;          /* into state 0 */
+        const double c00 = v0, c10 = v1;                      /* into state 0 (edge score 0) */
         const int b0 = c10 > c00;
         const double best0 = b0 ? c10 : c00;
-        const double c01 = v0 + 0.0, c11 = v1 + t[i - 1];     /* into state 1 */
+        const double c01 = v0, c11 = v1 + t[i - 1];           /* into state 1 */
         const int b1 = c11 > c01;
         const double best1 = b1 ? c11 : c01;
         from0[i] = (unsigned char)b0;
@@ -189,7 +190,7 @@ static double maximize_seq(const double* on, const double* off, const double* t,
         v0 = best0 + off[i];
         v1 = best1 + on[i];
     }
-    const double f0 = v0 + 0.0, f1 = v1 + 0.0;
+    const double f0 = v0, f1 = v1;
     int state = f1 > f0;
     const double value = state ? f1 : f0;
     for (int i = n - 1; i >= 0; --i) {

@@ -456,10 +456,10 @@ struct Sm {
             unsigned long long m0 = 0ull, m1 = 0ull;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const double c00 = v0 + 0.0, c10 = v1 + 0.0;      // into state 0
+                const double c00 = v0, c10 = v1;                   // into state 0 (edge score 0)
                 const bool b0 = (__ballot(c10 > c00) & 1ull) != 0ull;   // lane 0 is always active
                 const double best0 = b0 ? c10 : c00;
-                const double c01 = v0 + 0.0, c11 = v1 + t[u];      // into state 1
+                const double c01 = v0, c11 = v1 + t[u];            // into state 1
                 const bool b1 = (__ballot(c11 > c01) & 1ull) != 0ull;
                 const double best1 = b1 ? c11 : c01;
                 const double nv0 = best0 + f[u], nv1 = best1 + o[u];
@@ -483,7 +483,7 @@ struct Sm {
             for (; i0 + 8 <= n; i0 += 8) batch(i0, std::false_type{});
             if (i0 < n) batch(i0, std::true_type{});
         }
-        const double e0 = v0 + 0.0, e1 = v1 + 0.0;
+        const double e0 = v0, e1 = v1;
         bool state = (__ballot(e1 > e0) & 1ull) != 0ull;
         value = state ? e1 : e0;
         unsigned long long bits[NK];
