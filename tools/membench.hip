@@ -199,6 +199,60 @@ __global__ __launch_bounds__(256) void k_copy_pipe(const float4* __restrict__ a,
     }
 }
 
+// The K = 65536 forward's shape: 1024 threads hold a 256 KB tile in registers (16 float4 each),
+// `work` rounds of dependent VALU work stand in for the threshold search, then the tile is stored.
+// STAGE: persistent workgroups; while a tile is worked on and stored, the first half of the next
+// tile is already on its way into LDS (global_load_lds_dwordx4, no registers involved).
+__device__ __forceinline__ float burn(float v, int work)
+{
+    for (int i = 0; i < work; ++i) v = __builtin_fmaf(v, 1.0000001f, 1e-9f);
+    return v;
+}
+template <bool STAGE>
+__global__ __launch_bounds__(1024) void k_copy_wg(const float4* __restrict__ a, float4* __restrict__ o,
+                                                   size_t ntiles, int work)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(16) char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const f4* s4 = reinterpret_cast<const f4*>(a);
+    f4* d4 = reinterpret_cast<f4*>(o);
+    f4 v[16];
+    if (!STAGE) {
+        const size_t t = blockIdx.x;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(s4 + t * 16384 + u * 1024 + threadIdx.x);
+        v[0].x = burn(v[0].x + v[15].w, work);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], d4 + t * 16384 + u * 1024 + threadIdx.x);
+        return;
+    }
+    size_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    auto prefetch = [&](size_t tile) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            __builtin_amdgcn_global_load_lds(s4 + tile * 16384 + u * 1024 + wave * 64 + lane,
+                                             (__attribute__((address_space(3))) void*)(lds + (u * 16 + wave) * 1024), 16, 0, 0);
+    };
+    prefetch(t);
+    for (;;) {
+#pragma unroll
+        for (int u = 8; u < 16; ++u) v[u] = __builtin_nontemporal_load(s4 + t * 16384 + u * 1024 + threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the eight LDS loads were issued first
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f4*>(lds + (u * 16 + wave) * 1024 + lane * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const size_t tn = t + gridDim.x;
+        if (tn < ntiles) prefetch(tn);
+        v[0].x = burn(v[0].x + v[15].w, work);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) __builtin_nontemporal_store(v[u], d4 + t * 16384 + u * 1024 + threadIdx.x);
+        if (tn >= ntiles) break;
+        t = tn;
+    }
+}
+
 int main(int argc, char** argv)
 {
     size_t bytes = (size_t)16 << 30;  // per tensor
@@ -208,6 +262,22 @@ int main(int argc, char** argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
     double t;
+    if (argc > 5) {
+        const size_t nt = n / 16384;
+        CK(hipFuncSetAttribute((const void*)k_copy_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        CK(hipFuncSetAttribute((const void*)k_copy_wg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        for (int work : {0, 300, 1000}) {
+            t = timeit([&] { k_copy_wg<false><<<(unsigned)nt, 1024>>>(a, o, nt, work); });
+            printf("wg copy 256 KB tiles work=%d one tile per workgroup (two workgroups per CU): %.2f TB/s\n", work, 2.0 * bytes / t / 1e12);
+            t = timeit([&] { k_copy_wg<false><<<(unsigned)nt, 1024, 128 * 1024>>>(a, o, nt, work); });
+            printf("wg copy 256 KB tiles work=%d one tile per workgroup, one workgroup per CU (as the forward): %.2f TB/s\n", work, 2.0 * bytes / t / 1e12);
+            for (int g : {256, 512}) {
+                t = timeit([&] { k_copy_wg<true><<<g, 1024, 128 * 1024>>>(a, o, nt, work); });
+                printf("wg copy 256 KB tiles work=%d staged through LDS, grid=%d: %.2f TB/s\n", work, g, 2.0 * bytes / t / 1e12);
+            }
+        }
+        return 0;
+    }
     if (argc > 4) {
         const size_t ntiles = n / (64 * 16);
 #define PP(MODE, RM, G) t = timeit([&] { k_copy_pipe<16, MODE, RM><<<G, 256>>>(a, o, ntiles); }); \
