@@ -273,3 +273,39 @@ def test_sequence_factor_many_swaps(dev, oracle_mod, n):
             assert np.array_equal(out[key].cpu().numpy(), ref[key]), (key, mi)
         assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
     assert (ref["iters"] == 5).any()
+
+
+def test_fuzz_over_shapes_budgets_and_limits(dev, oracle_mod):
+    """48 random problems (1 ... 128 bits, any budget, score scales 0.2 ... 4, with and without
+    init scores, iteration limits 1 ... 300, integer-valued scores in a quarter of them) and 16
+    random chains: everything the solver returns is identical to the oracle."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(20260)
+    for trial in range(64):
+        seq = trial >= 48
+        n = int(rng.integers(2 if seq else 1, 129))
+        B = int(rng.integers(1, 97))
+        sigma = float(rng.choice([0.2, 0.5, 1.0, 2.0, 4.0]))
+        budget = 0 if (seq or rng.random() < 0.4) else int(rng.integers(1, n + 1))
+        max_iter = int(rng.choice([1, 3, 17, 100, 300]))
+        use_init = bool(rng.random() < 0.7)
+        x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+        if trial % 4 == 3:
+            x = np.round(x)
+        init = rng.random((B, 2 * n)) if use_init else None
+        it = torch.from_numpy(init).to(dev) if use_init else None
+        if seq:
+            t = (sigma * rng.standard_normal((B, n - 1))).astype(np.float32)
+            ref = oracle_mod.sparsemap_seq_fwd(x, t, init, max_iter=max_iter)
+            out = _native.sparsemap_seq_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev), it, max_iter)
+        else:
+            ref = oracle_mod.sparsemap_fwd(x, init, budget, max_iter)
+            out = _native.sparsemap_fwd(torch.from_numpy(x).to(dev), it, budget, max_iter)
+        tag = (trial, n, B, sigma, budget, max_iter, use_init)
+        for key in ("status", "iters", "alen", "p"):
+            assert np.array_equal(out[key].cpu().numpy(), ref[key]), (key, tag)
+        assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"]), tag
+        inv = out["inv_a"].cpu().numpy()
+        for b in range(0, B, 7):
+            m = ref["alen"][b]
+            assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1]), tag
