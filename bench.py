@@ -37,6 +37,7 @@ Extra objects on that line:
                 config 5 with the flat-bucket gradient all-reduce over RCCL); config 2 also in the
                 support-only and hoisted-decoder modes
   sparsemap_cpu_baseline  the fp64 C oracle of the solver timed on one host core, same workload
+  sparsemap_cpu_baseline_all_cores  the same on every host thread of this process
 """
 import argparse
 import json
@@ -318,6 +319,31 @@ def sparsemap_cpu_baseline(B, n, budget, sigma):
             "active_set_iters_per_s": float(ref["iters"].sum()) / t,
             "sample": f"{B} samples x {n} bits, budget {budget}, N(0,{sigma}^2) scores, "
                       f"oracle/sparsemap_oracle.c forward, {t:.1f} s on 1 of {os.cpu_count()} host cores"}
+
+
+def sparsemap_cpu_baseline_all_cores(B, n, budget, sigma):
+    """the all-cores variant -- the same C oracle on every host thread this process
+    may use (ctypes releases the GIL; the batch is split into one slice per thread)."""
+    import numpy as np
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(torch.get_num_threads(), os.cpu_count() or 1))
+    rng = np.random.default_rng(78)
+    x = (sigma * rng.standard_normal((B, n))).astype(np.float32)
+    init = torch.rand(B, 2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(43)).numpy()
+    cuts = np.linspace(0, B, threads + 1).astype(int)
+    oracle.lib()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda i: oracle.sparsemap_fwd(np.ascontiguousarray(x[cuts[i]:cuts[i + 1]]),
+                                                         np.ascontiguousarray(init[cuts[i]:cuts[i + 1]]),
+                                                         budget, 300), range(threads)))
+    t = time.perf_counter() - t0
+    iters = float(sum(r["iters"].sum() for r in res))
+    return {"value": B / t, "unit": "samples/s", "cores": threads, "kind": "port",
+            "active_set_iters_per_s": iters / t,
+            "sample": f"{B} samples x {n} bits, budget {budget}, N(0,{sigma}^2) scores, "
+                      f"oracle/sparsemap_oracle.c forward on {threads} threads of {os.cpu_count()} host cores, {t:.1f} s"}
 
 
 def topk_bench(native, dev, B, n, k, reps=20, cpu=True):
@@ -718,6 +744,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.K, a.sigma)
         out["cpu_baseline_torch_all_cores"] = cpu_baseline_torch(a.K, a.sigma)
         out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(8192, 128, 0, 1.0)   # ~5 s on one core
+        out["sparsemap_cpu_baseline_all_cores"] = sparsemap_cpu_baseline_all_cores(32768, 128, 0, 1.0)
     if rank == 0:
         print(json.dumps(out))
     if _dist_on():
