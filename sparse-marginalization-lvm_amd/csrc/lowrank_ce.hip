@@ -233,23 +233,40 @@ __global__ __launch_bounds__(256) void lowrank_ce_bwd_dw_kernel(
     }
     const f32x2 k2 = splat(kLog2e);
     constexpr int kPerWave = kDwTile / 4;
+    static_assert(kDwTile == 256, "one pair of the tile per thread");
     const int64_t tiles = (P + kDwTile - 1) / kDwTile;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    // The next tile travels from HBM into registers while the current one is worked on from LDS
+    // (two workgroups per CU do not cover a tile's load latency between two barriers).
+    float nx[R], nl = 0.0f, ng = 0.0f;
+    int ny = -1;
+    auto fetch = [&](int64_t t) {
         const int64_t p0 = t * kDwTile;
         const int cnt = (int)((P - p0 < kDwTile) ? (P - p0) : kDwTile);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            nx[j] = (i / R) < cnt ? X[p0 * R + i] : 0.0f;
+        }
+        const bool ok = (int)threadIdx.x < cnt;
+        const int64_t p = ok ? p0 + threadIdx.x : p0;
+        nl = lse[p] * kLog2e;
+        ng = ok ? gloss[p / F] : 0.0f;   // padding contributes nothing
+        ny = ok ? label_at<YT>(y, p, C) : -1;
+    };
+    if ((int64_t)blockIdx.x < tiles) fetch(blockIdx.x);
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         __syncthreads();  // previous tile fully consumed
-        for (int i = threadIdx.x; i < kDwTile * R; i += 256) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int i = threadIdx.x + 256 * j;
             const int pix = i / R, r = i - pix * R;
-            xs[r * kDwTile + pix] = pix < cnt ? X[p0 * R + i] : 0.0f;
+            xs[r * kDwTile + pix] = nx[j];
         }
-        if (threadIdx.x < kDwTile) {
-            const bool ok = threadIdx.x < cnt;
-            const int64_t p = ok ? p0 + threadIdx.x : p0;
-            ls[threadIdx.x] = lse[p] * kLog2e;
-            gs[threadIdx.x] = ok ? gloss[p / F] : 0.0f;   // padding contributes nothing
-            ys[threadIdx.x] = ok ? label_at<YT>(y, p, C) : -1;
-        }
+        ls[threadIdx.x] = nl;
+        gs[threadIdx.x] = ng;
+        ys[threadIdx.x] = ny;
         __syncthreads();
+        if (t + gridDim.x < tiles) fetch(t + gridDim.x);
 #pragma unroll 2
         for (int ii = 0; ii < kPerWave; ii += 2) {
             const int i = wave * kPerWave + ii;
