@@ -154,8 +154,15 @@ def lowrank_categorical_nll(x, w, b, y):
     return _LowRankCE.apply(x.contiguous(), w.contiguous(), b.contiguous(), y)
 
 
+_NARROW = (torch.float16, torch.bfloat16)
+
+
 def sparsemax(X, dim=-1):
-    """entmax.sparsemax replacement: Euclidean projection of each slice along `dim` onto the simplex."""
+    """entmax.sparsemax replacement: Euclidean projection of each slice along `dim` onto the simplex.
+    The kernels compute in fp32; half / bfloat16 inputs (autocast) are widened, and the result
+    comes back in the input's dtype (float64 is refused rather than silently narrowed)."""
+    if X.dtype in _NARROW:
+        return sparsemax(X.float(), dim).to(X.dtype)
     if dim < 0:
         dim += X.dim()
     if dim != X.dim() - 1:
@@ -167,7 +174,10 @@ def sparsemax(X, dim=-1):
 
 
 def entmax15(X, dim=-1):
-    """entmax.entmax15 replacement: p = max(X/2 - tau, 0)^2 along `dim`, sum p = 1."""
+    """entmax.entmax15 replacement: p = max(X/2 - tau, 0)^2 along `dim`, sum p = 1 (fp32 kernels;
+    half / bfloat16 inputs are widened as in `sparsemax`)."""
+    if X.dtype in _NARROW:
+        return entmax15(X.float(), dim).to(X.dtype)
     if dim < 0:
         dim += X.dim()
     if dim != X.dim() - 1:

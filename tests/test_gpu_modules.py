@@ -214,7 +214,7 @@ def test_sequence_smap_as_the_reference_drives_it(dev, oracle_mod):
     t = torch.randn(n - 1, generator=g).to(dev).requires_grad_(True)
     torch.manual_seed(8)
     p, aset = sm.sequence_smap(x, t)
-    assert not aset.requires_grad and aset.shape == (p.shape[0], n) and abs(float(p.sum()) - 1) < 1e-6
+    assert not aset.requires_grad and aset.shape == (p.shape[0], n) and abs(float(p.detach().sum()) - 1) < 1e-6
     w = torch.randn(p.shape[0], generator=g).to(dev)
     gx, gt = torch.autograd.grad((p * w).sum(), (x, t))
     torch.manual_seed(8)
@@ -312,6 +312,27 @@ def test_entmax_shim(dev, oracle_mod):
     assert np.allclose(xt.grad.cpu().numpy(), g_ref, atol=1e-6)
     p15 = entmax.entmax15(torch.from_numpy(x).to(dev), dim=-1)
     assert torch.allclose(p15.sum(-1), torch.ones(64, device=dev), atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_narrow_dtypes_are_widened_and_float64_refused(dev, dtype):
+    """Autocast hands the normalisers half / bfloat16 logits: they are computed in fp32 (the
+    kernels' arithmetic) and come back in the input's dtype, gradients included; float64 is
+    refused instead of being narrowed without notice."""
+    from lvmhelpers import functional as F_
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(33, 50, generator=g).to(dtype).to(dev)
+    for fn in (F_.sparsemax, F_.entmax15):
+        xn = x.clone().requires_grad_(True)
+        xw = x.float().requires_grad_(True)
+        pn, pw = fn(xn, dim=-1), fn(xw, dim=-1)
+        assert pn.dtype == dtype and torch.equal(pn, pw.to(dtype))
+        dy = torch.randn(33, 50, generator=g).to(dev)
+        (pn.float() * dy).sum().backward()
+        (pw.to(dtype).float() * dy).sum().backward()
+        assert xn.grad.dtype == dtype and torch.equal(xn.grad, xw.grad.to(dtype))
+        with pytest.raises(TypeError):
+            fn(x.double(), dim=-1)
 
 
 @pytest.mark.parametrize("K,coeff", [(10, 1.0), (256, 0.1)])
