@@ -1,7 +1,7 @@
 """GPU box: randomized parity soak with FRESH seeds (the test suite's seeds are fixed): sparsemax
 forward (p, supp bit-exact), list backward (against the p-based backward and the oracle), the
 compaction lists, the SparseMAP solver and the sequence factor (everything identical to the oracle).
-    python tools/soak.py [seconds] [seed]
+    python tools/soak.py [seconds] [seed] [other]     (other: k-best bit vectors and entmax15 instead)
 Prints one line per 50 trials and every mismatch with what reproduces it; exit status 1 on any."""
 import sys
 import time
@@ -104,11 +104,58 @@ def sparsemap_trial(rng, trial):
               f"max_iter {max_iter} init {use_init} q {q:.2f}", flush=True)
 
 
+def topk_trial(rng, trial):
+    global bad
+    n = int(rng.integers(1, 200))
+    k = int(rng.integers(2, 65))
+    if n < 7:
+        k = min(k, 1 << n)
+    if k < 2:
+        return
+    B = int(rng.integers(1, 300))
+    sc = (float(rng.choice([0.1, 1.0, 5.0])) * rng.standard_normal((B, n))).astype(np.float32)
+    q = rng.random()
+    if q < 0.3:
+        sc = np.round(sc * 2) / 2
+    elif q < 0.4:
+        sc[:] = 0.0
+    cfg_ref, top_ref = oracle.binary_topk_batched(sc, k)
+    cfg, top = _native.binary_topk_batched(torch.from_numpy(sc).to(dev), k, want_scores=True)
+    if not (np.array_equal(top.cpu().numpy(), top_ref) and np.array_equal(cfg.cpu().numpy(), cfg_ref)):
+        bad += 1
+        print(f"MISMATCH topk: trial {trial} B {B} n {n} k {k} q {q:.2f}", flush=True)
+
+
+def entmax15_trial(rng, trial):
+    """floating point: p to 2e-6, dx to 2e-5 of the row scale (tests/test_gpu_entmax15.py)"""
+    global bad
+    K = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1100), rng.integers(1100, 4200),
+                        rng.integers(4200, 65537)]))
+    R = int(rng.integers(1, max(2, min(200, (1 << 20) // K))))
+    x, tag = rows(rng, R, K)
+    if tag[0] == 3:
+        return   # offsets of 1e4 ... 3e7: x / 2 - max is exact but the oracle's fp32 sort/cumsum is not the bar there
+    p_ref = oracle.entmax15_fwd(x)[0]
+    p = _native.entmax15_fwd(torch.from_numpy(x).to(dev))[0]
+    dy = rng.standard_normal((R, K)).astype(np.float32)
+    dx = _native.entmax15_bwd(torch.from_numpy(dy).to(dev), p).cpu().numpy()
+    dx_ref = oracle.entmax15_bwd(dy, p.cpu().numpy())
+    e_p = np.abs(p.cpu().numpy() - p_ref).max()
+    e_dx = np.abs(dx - dx_ref).max() / max(1e-30, np.abs(dy).max())
+    if not (e_p <= 2e-6 and e_dx <= 2e-5):
+        bad += 1
+        print(f"MISMATCH entmax15: trial {trial} R {R} K {K} kind/sigma {tag} p err {e_p:.2e} dx err {e_dx:.2e}",
+              flush=True)
+
+
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 t0 = time.time()
 trial = 0
 while time.time() - t0 < budget_s:
     rng = np.random.default_rng([seed0, trial])
-    if trial % 3 == 2:
+    if only == "other":
+        (topk_trial if trial % 2 else entmax15_trial)(rng, trial)
+    elif trial % 3 == 2:
         sparsemap_trial(rng, trial)
     else:
         sparsemax_trial(rng, trial)
