@@ -718,3 +718,54 @@ def test_wide_rows_carry_lists_of_up_to_128_columns(dev, oracle_mod, K, sigma):
                                       ctypes.c_int64(1), ctypes.c_int32(K), None) == -1
     assert L.smlvm_sparsemax_fwd_cols(one, one, one, None, None, None, one, ctypes.c_int32(128), None,
                                       ctypes.c_int64(1), ctypes.c_int32(4096), None) == -1
+
+
+@pytest.mark.parametrize("K", [10, 256, 1000, 4096, 8192, 65536, 100000])
+def test_masked_logits_minus_inf(dev, oracle_mod, K):
+    """Logits masked with -inf (the usual way to exclude classes; entmax's sort / cumsum leaves them
+    out of the support): every kernel family gives the sparsemax of the finite entries, zeros at the
+    masked ones, and a finite gradient that is zero there -- including a row with one finite entry."""
+    from lvmhelpers import functional as F_
+    rng = np.random.default_rng(K)
+    R = 8
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    m = rng.random((R, K)) < 0.5
+    m[:, 0] = False
+    x[m] = -np.inf
+    x[1, 1:] = -np.inf
+    p_ref, _, _, _ = oracle_mod.sparsemax_fwd(x)
+    for r in range(R):
+        f = ~np.isinf(x[r])
+        sub, _, _, _ = oracle_mod.sparsemax_fwd(x[r:r + 1, f])
+        assert np.array_equal(sub[0], p_ref[r, f]) and np.all(p_ref[r, ~f] == 0)
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    p = F_.sparsemax(xt, dim=-1)
+    dy = torch.randn(R, K, device=dev)
+    (p * dy).sum().backward()
+    assert np.array_equal(p.detach().cpu().numpy(), p_ref)
+    g = xt.grad.cpu().numpy()
+    assert np.isfinite(g).all() and np.all(g[np.isinf(x)] == 0)
+    assert p_ref[1, 0] == 1.0
+
+
+@pytest.mark.parametrize("K", [10, 256, 4096, 8192, 65536])
+def test_masked_logits_minus_inf_entmax15(dev, oracle_mod, K):
+    """The same for entmax15 (floating point: 2e-6 on p against the oracle on the finite entries)."""
+    from lvmhelpers import functional as F_
+    rng = np.random.default_rng(K + 1)
+    R = 6
+    x = rng.standard_normal((R, K)).astype(np.float32)
+    m = rng.random((R, K)) < 0.5
+    m[:, 0] = False
+    x[m] = -np.inf
+    x[1, 1:] = -np.inf
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    p = F_.entmax15(xt, dim=-1)
+    (p * torch.randn(R, K, device=dev)).sum().backward()
+    pn = p.detach().cpu().numpy()
+    for r in range(R):
+        f = ~np.isinf(x[r])
+        sub = oracle_mod.entmax15_fwd(x[r:r + 1, f])[0]
+        assert np.abs(pn[r, f] - sub[0]).max() <= 2e-6 and np.all(pn[r, ~f] == 0)
+    g = xt.grad.cpu().numpy()
+    assert np.isfinite(g).all() and np.all(g[np.isinf(x)] == 0)
