@@ -435,3 +435,25 @@ def test_hoisting_hook_protocol(dev):
     with pytest.raises(TypeError):
         Marginalizer(ExplicitWrapper(enc, normalizer="sparsemax"), DeterministicWrapper(CatDecoder(K, D).to(dev)),
                      cat_loss, compact=True, hoist=True)(x, x, labels)
+
+
+def test_empty_batches(dev):
+    """Zero rows / samples go through every wrapper of the path: empty outputs of the right shapes,
+    no launch, no error (the last, ragged shard of a data-parallel split can be empty)."""
+    from lvmhelpers import _native, functional as F_
+    x = torch.empty(0, 17, device=dev, requires_grad=True)
+    for fn in (F_.sparsemax, F_.entmax15):
+        p = fn(x, dim=-1)
+        assert tuple(p.shape) == (0, 17)
+        p.sum().backward()
+        assert tuple(x.grad.shape) == (0, 17)
+    p = torch.empty(0, 17, device=dev)
+    off, rows, cols, vals = _native.support_compact(p)
+    assert off.tolist() == [0] and rows.numel() == cols.numel() == vals.numel() == 0
+    cfg, top = _native.binary_topk_batched(torch.empty(0, 12, device=dev), 4, want_scores=True)
+    assert tuple(cfg.shape) == (0, 4, 12) and tuple(top.shape) == (0, 4)
+    out = _native.sparsemap_fwd(torch.empty(0, 12, device=dev), None, 0, 10)
+    assert tuple(out["p"].shape) == (0, 13) and out["alen"].numel() == 0
+    loss, lse, nll = _native.lowrank_ce_fwd(torch.empty(0, 5, 3, device=dev), torch.randn(7, 3, device=dev),
+                                            torch.randn(7, device=dev), torch.empty(0, 5, dtype=torch.uint8, device=dev))
+    assert loss.numel() == 0 and tuple(lse.shape) == (0, 5)
