@@ -1307,6 +1307,94 @@ __device__ __forceinline__ void bwd_tile_from_cols(const float* __restrict__ dyr
     }
 }
 
+// dx of a row whose non-zero pattern the forward left as one bit per register (kColsMask), support
+// small enough to gather.  Walking the pattern register by register costs one masked load
+// instruction per occupied register slot -- ~38 per row at 58 non-zeros, one or two live lanes
+// each, and the CU's one address unit takes them one after the other.  Here the pattern is first
+// compacted into a column list in LDS (lane-exclusive prefix of the popcounts, every lane then
+// writes its own few columns), the whole list is gathered with one or two full-lane loads, and dx
+// is assembled 1024 columns at a time in an LDS tile (zero but for the scattered values) that is
+// read back as float4s and stored -- every byte of dx written once, with full-width stores.
+// wl: this wave's LDS (kPatLdsWords words).  Returns false (nothing written) if the pattern holds
+// more than kPatList columns: the caller falls back to the register walk.
+constexpr int kPatList = 128;                      // list slots (two per lane)
+constexpr int kPatTile = 1024;                     // columns assembled per step
+constexpr int kPatLdsWords = kPatTile + kPatList;  // per wave
+template <int E>
+__device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow, float* __restrict__ dxrow,
+                                                 int c0, int c1, int s, int K, int lane, bool live,
+                                                 WaveRed<64>& red, float* wl);
+template <int E>
+__device__ __forceinline__ bool bwd_row_from_pattern(const float* __restrict__ dyrow, float* __restrict__ dxrow,
+                                                     uint2 m, int s, int K, int lane, bool live,
+                                                     WaveRed<64>& red, float* wl)
+{
+    static_assert(E % 16 == 0, "whole 1024-column steps");
+    float* tile = wl;
+    int* lcols = reinterpret_cast<int*>(wl + kPatTile);
+    const int cnt = __popc(m.x) + __popc(m.y);
+    int incl = group_scan_incl<16>(cnt, lane & 15);
+    const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31),
+              t2 = __builtin_amdgcn_readlane(incl, 47);
+    incl += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total > kPatList) return false;   // wave-uniform
+    // zero tile (4 float4 per lane) and this lane's columns, in register order
+    float4* tile4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+    for (int i = 0; i < kPatTile / 256; ++i) tile4[i * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned long long bits = ((unsigned long long)m.y << 32) | m.x;
+    int off = incl - cnt;
+    while (__ballot(bits != 0ull) != 0ull) {
+        if (bits != 0ull) {
+            const int e = __ffsll((long long)bits) - 1;
+            bits &= bits - 1ull;
+            lcols[off++] = (((e >> 2) * 64 + lane) << 2) + (e & 3);   // col_of<E, true>(e, lane, 64)
+        }
+    }
+    wave_lds_sync();
+    const int c0 = lane < total ? lcols[lane] : -1;
+    const int c1 = lane + 64 < total ? lcols[lane + 64] : -1;
+    bwd_row_assemble<E>(dyrow, dxrow, c0, c1, s, K, lane, live, red, wl);
+    return true;
+}
+
+// (second half of the above, also usable with a list the forward wrote: c0 / c1 = this lane's
+// columns or -1; the tile must be all zero on entry and is left all zero)
+template <int E>
+__device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow, float* __restrict__ dxrow,
+                                                 int c0, int c1, int s, int K, int lane, bool live,
+                                                 WaveRed<64>& red, float* wl)
+{
+    float* tile = wl;
+    float4* tile4 = reinterpret_cast<float4*>(tile);
+    float v0 = 0.0f, v1 = 0.0f;
+    if (c0 >= 0) v0 = dyrow[c0];
+    if (c1 >= 0) v1 = dyrow[c1];
+    const double acc = red.sum((double)v0 + (double)v1);
+    const float mean = (float)acc / (float)s;
+    v0 -= mean;
+    v1 -= mean;
+    float4* dx4 = reinterpret_cast<float4*>(dxrow);
+    const int K4 = K >> 2;
+#pragma unroll
+    for (int q = 0; q < E / 16; ++q) {
+        const bool h0 = c0 >= 0 && (c0 >> 10) == q, h1 = c1 >= 0 && (c1 >> 10) == q;
+        if (h0) tile[c0 & (kPatTile - 1)] = v0;
+        if (h1) tile[c1 & (kPatTile - 1)] = v1;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < kPatTile / 256; ++i) {
+            const float4 t = tile4[i * 64 + lane];
+            const int f = q * (kPatTile / 4) + i * 64 + lane;   // float4 index in the row
+            if (live && f < K4) nt_store4(dx4 + f, t);
+        }
+        wave_lds_sync();
+        if (h0) tile[c0 & (kPatTile - 1)] = 0.0f;
+        if (h1) tile[c1 & (kPatTile - 1)] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------- kernels
 constexpr int kWavesPerBlock = 4;
 
@@ -1527,10 +1615,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     const int head = list[0];
     WaveRed<G> red;
     constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
+    __shared__ __align__(16) float pat_lds[MASKS ? kWavesPerBlock * kPatLdsWords : 1];
     if constexpr (MASKS) {
         // no list, but the forward left the non-zero pattern (head and s are wave-uniform here)
         if (mask && head == kColsMask) {
             const uint2 m = reinterpret_cast<const uint2*>(mask + row * kMaskWordsPerRow)[lane];
+            if (s <= gather_max(K) &&
+                bwd_row_from_pattern<E>(dy + row * K, dx + row * K, m, s, K, lane, live, red,
+                                        pat_lds + (threadIdx.x >> 6) * kPatLdsWords))
+                return;
             float a[E];
             if (s <= gather_max(K)) {
 #pragma unroll
@@ -1583,7 +1676,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
             bwd_tile_from_cols<E, G, VEC>(dy + row * K, list, cap, gl, lane, s, red, a);
             if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
         } else {
-            bwd_row_from_cols<E, G, VEC, FULL>(dy + row * K, dx + row * K, list, cap, K, gl, s, live, red);
+            if constexpr (MASKS) {
+                // 16-byte rows of 1025 ... 4096 columns: dx is assembled in the wave's LDS tile and
+                // written once with full-width stores (zero fill + scattered 4-byte stores and the
+                // wait between them: 3.37 -> 2.9-3.0 ms at 1M x 4096, 4.13 -> 3.23 ms at 17 entries)
+                float* wl = pat_lds + (threadIdx.x >> 6) * kPatLdsWords;
+                float4* tile4 = reinterpret_cast<float4*>(wl);
+#pragma unroll
+                for (int i = 0; i < kPatTile / 256; ++i) tile4[i * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const int c0 = lane < cap ? list[lane] : kColsNone;
+                bwd_row_assemble<E>(dy + row * K, dx + row * K, c0, kColsNone, s, K, lane, live, red, wl);
+            } else {
+                bwd_row_from_cols<E, G, VEC, FULL>(dy + row * K, dx + row * K, list, cap, K, gl, s, live, red);
+            }
         }
     } else if (__ballot(s > gather_max(K)) == 0ull) {
         float a[E];
