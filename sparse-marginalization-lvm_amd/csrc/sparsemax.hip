@@ -1323,7 +1323,7 @@ constexpr int kPatLdsWords = kPatTile + kPatList;  // per wave
 template <int E>
 __device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow, float* __restrict__ dxrow,
                                                  int c0, int c1, int s, int K, int lane, bool live,
-                                                 WaveRed<64>& red, float* wl);
+                                                 WaveRed<64>& red, float* wl, int col_base = 0);
 template <int E>
 __device__ __forceinline__ bool bwd_row_from_pattern(const float* __restrict__ dyrow, float* __restrict__ dxrow,
                                                      uint2 m, int s, int K, int lane, bool live,
@@ -1360,11 +1360,13 @@ __device__ __forceinline__ bool bwd_row_from_pattern(const float* __restrict__ d
 }
 
 // (second half of the above, also usable with a list the forward wrote: c0 / c1 = this lane's
-// columns or -1; the tile must be all zero on entry and is left all zero)
+// columns or -1; the tile must be all zero on entry and is left all zero.  The E columns from
+// col_base on are written -- one 4096-column segment of a wider row -- while the mean is taken
+// over the whole list.)
 template <int E>
 __device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow, float* __restrict__ dxrow,
                                                  int c0, int c1, int s, int K, int lane, bool live,
-                                                 WaveRed<64>& red, float* wl)
+                                                 WaveRed<64>& red, float* wl, int col_base)
 {
     float* tile = wl;
     float4* tile4 = reinterpret_cast<float4*>(tile);
@@ -1379,19 +1381,20 @@ __device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow
     const int K4 = K >> 2;
 #pragma unroll
     for (int q = 0; q < E / 16; ++q) {
-        const bool h0 = c0 >= 0 && (c0 >> 10) == q, h1 = c1 >= 0 && (c1 >> 10) == q;
-        if (h0) tile[c0 & (kPatTile - 1)] = v0;
-        if (h1) tile[c1 & (kPatTile - 1)] = v1;
+        const int r0 = c0 - col_base, r1 = c1 - col_base;   // (columns below the base shift to negative)
+        const bool h0 = c0 >= 0 && (r0 >> 10) == q, h1 = c1 >= 0 && (r1 >> 10) == q;
+        if (h0) tile[r0 & (kPatTile - 1)] = v0;
+        if (h1) tile[r1 & (kPatTile - 1)] = v1;
         wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < kPatTile / 256; ++i) {
             const float4 t = tile4[i * 64 + lane];
-            const int f = q * (kPatTile / 4) + i * 64 + lane;   // float4 index in the row
+            const int f = (col_base >> 2) + q * (kPatTile / 4) + i * 64 + lane;   // float4 index in the row
             if (live && f < K4) nt_store4(dx4 + f, t);
         }
         wave_lds_sync();
-        if (h0) tile[c0 & (kPatTile - 1)] = 0.0f;
-        if (h1) tile[c1 & (kPatTile - 1)] = 0.0f;
+        if (h0) tile[r0 & (kPatTile - 1)] = 0.0f;
+        if (h1) tile[r1 & (kPatTile - 1)] = 0.0f;
     }
 }
 
@@ -1709,6 +1712,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
 // (same fp64 sum in every wave), zero-fills its own segment and, once those stores are in the L2,
 // stores the values whose columns fall into it -- no synchronisation between the waves of a row.
 // Rows without a list are left to sparsemax_bwd_block_kernel (launched after this one).
+constexpr int kSegTileMinSupport = 16;
 template <bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segment_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ cols, int cap,
@@ -1727,6 +1731,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segmen
     const int c2 = lane + 64 < cap ? cols[row * cap + lane + 64] : kColsNone;   // cap <= kColsMaxCapWide
     if (__builtin_amdgcn_readfirstlane(c) == kColsOverflow) return;
     float* dxrow = dx + row * K;
+    const bool in1 = c >= 0 && (c >> 12) == seg, in2 = c2 >= 0 && (c2 >> 12) == seg;
+    const bool mine = __ballot(in1 || in2) != 0ull;   // does a listed column fall into this segment?
+    const int s_row = supp[row];
+    if constexpr (VEC) {
+        // Short lists keep the two rounds of stores below (the zero fill leaves at once, without
+        // waiting for the gathers: 1.53 against 1.60 ms at 32768 x 65536, support 5); longer ones
+        // are assembled in the wave's LDS tile and stored once (support 60-70: K = 65536 1.83 ->
+        // 1.70 ms, K = 16384 2.28 -> 1.89 ms, K = 8196 0.79 -> 0.61 ms).
+        if (mine && s_row > kSegTileMinSupport) {
+            __shared__ __align__(16) float pat_lds[kWavesPerBlock * kPatLdsWords];
+            float* wl = pat_lds + wave * kPatLdsWords;
+            float4* tile4 = reinterpret_cast<float4*>(wl);
+#pragma unroll
+            for (int i = 0; i < kPatTile / 256; ++i) tile4[i * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            WaveRed<64> red;
+            bwd_row_assemble<64>(dy + row * K, dxrow, c, c2, s_row, K, lane, true, red, wl, seg * SEG);
+            return;
+        }
+    }
     {
         float zero[64];
 #pragma unroll
@@ -1740,17 +1763,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void sparsemax_bwd_cols_segmen
                 __builtin_amdgcn_raw_buffer_store_b32(0, rs, (seg * SEG + e * 64 + lane) * 4, 0, 0);
         }
     }
+    if (!mine) return;   // an all-zero segment: nothing to gather, nothing to wait for
     const float v = c >= 0 ? dy[row * K + c] : 0.0f;
     const float v2 = c2 >= 0 ? dy[row * K + c2] : 0.0f;
     WaveRed<64> red;
     // (fp64 sum of <= 128 fp32 values by the wave's tree: differs from the streaming kernel's
     // column order by fp64 rounding only, far below the fp32 result)
     const double acc = red.sum((double)v + (double)v2);
-    const float mean = (float)acc / (float)supp[row];
+    const float mean = (float)acc / (float)s_row;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (c >= 0 && (c >> 12) == seg) dxrow[c] = v - mean;
-    if (c2 >= 0 && (c2 >> 12) == seg) dxrow[c2] = v2 - mean;
+    if (in1) dxrow[c] = v - mean;
+    if (in2) dxrow[c2] = v2 - mean;
 }
 
 template <int NW, int E, bool VEC, bool FULL>
