@@ -1618,7 +1618,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
     const int head = list[0];
     WaveRed<G> red;
     constexpr bool MASKS = (G == 64) && VEC && (E >= 32);
-    __shared__ __align__(16) float pat_lds[MASKS ? kWavesPerBlock * kPatLdsWords : 1];
+    constexpr bool SMALLTILE = VEC && (E <= 16) && (E >= 4);   // rows of <= 1024 columns, see below
+    __shared__ __align__(16) float pat_lds[MASKS ? kWavesPerBlock * kPatLdsWords
+                                                 : (SMALLTILE ? kWavesPerBlock * 64 * E : 1)];
     if constexpr (MASKS) {
         // no list, but the forward left the non-zero pattern (head and s are wave-uniform here)
         if (mask && head == kColsMask) {
@@ -1674,7 +1676,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, bwd_cols_waves_per_eu(E)) void
         }
     }
     if (__ballot(head < kColsNone) == 0ull) {   // every row of this wave has its list
-        if constexpr (E <= 16) {
+        if constexpr (SMALLTILE) {
+            // the wave's 64 / G rows side by side in its LDS tile (E G words each): zero, scatter
+            // the listed dy - mean, read back as the float4s store_row writes
+            constexpr int MAXS = kColsMaxCap / G;
+            float* wl = pat_lds + (threadIdx.x >> 6) * (64 * E);
+            float4* tile4 = reinterpret_cast<float4*>(wl);
+#pragma unroll
+            for (int i = 0; i < E / 4; ++i) tile4[i * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            int c[MAXS];
+            float v[MAXS];
+            double acc = 0.0;
+            const float* dyrow = dy + row * K;
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q) {
+                const int j = gl + G * q;
+                c[q] = (j < cap) ? list[j] : kColsNone;
+                v[q] = 0.0f;
+                if (c[q] >= 0) v[q] = dyrow[c[q]];
+                acc += (double)v[q];
+            }
+            acc = red.sum(acc);
+            const float mean = (float)acc / (float)s;
+            float* myrow = wl + (lane / G) * (E * G);
+#pragma unroll
+            for (int q = 0; q < MAXS; ++q)
+                if (c[q] >= 0) myrow[c[q]] = v[q] - mean;
+            wave_lds_sync();
+            float a[E];
+            const float4* my4 = reinterpret_cast<const float4*>(myrow);
+#pragma unroll
+            for (int i = 0; i < E / 4; ++i) {
+                const float4 t = my4[i * G + gl];
+                a[4 * i] = t.x; a[4 * i + 1] = t.y; a[4 * i + 2] = t.z; a[4 * i + 3] = t.w;
+            }
+            if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);
+        } else if constexpr (E <= 16) {
             float a[E];
             bwd_tile_from_cols<E, G, VEC>(dy + row * K, list, cap, gl, lane, s, red, a);
             if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, a);

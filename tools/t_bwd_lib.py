@@ -1,5 +1,6 @@
 """GPU box: list / pattern backward of the headline shape for the tree's library and others:
-python tools/t_bwd_lib.py [lib.so ...]   (N(0,1), N(0,0.2^2), N(0,0.05^2) at 1M x 4096)"""
+python tools/t_bwd_lib.py [lib.so ...]   (N(0,1), N(0,0.2^2), N(0,0.05^2) at 1M x 4096; T_R / T_K in the
+environment for another shape)"""
 import os, subprocess, sys
 if sys.argv[1:2] != ["--one"]:
     for lib in ["tree"] + sys.argv[1:]:
@@ -12,7 +13,7 @@ from lvmhelpers import _native
 if sys.argv[1] != "tree":
     _native.LIB_PATH = os.path.abspath(sys.argv[1])
 dev = torch.device('cuda:0')
-R, K = 1 << 20, 4096
+R, K = int(os.environ.get('T_R', 1 << 20)), int(os.environ.get('T_K', 4096))
 for sigma in (1.0, 0.2, 0.05):
     g = torch.Generator(device=dev).manual_seed(99)
     x = torch.empty(R, K, device=dev).normal_(0.0, sigma, generator=g)
