@@ -56,7 +56,7 @@ int smlvm_sparsemax_bwd(const float* dy, const float* p, const int32_t* supp_siz
                         int64_t R, int32_t K, void* stream);
 
 /* The same pair with a by-product that lets the backward skip p: the forward also writes the
- * columns of the non-zeros of every row, the backward gathers dy at those columns and zero-fills dx
+ * columns of the non-zeros of every row, the backward gathers dy at those columns and writes dx once
  * (no read of p, no streaming read of dy: the backward of sparsemax is O(support) reads + one dense
  * write).  What entmax keeps on the autograd ctx is (supp_size, p); this keeps (supp_size, lists).
  *   support_cols [R, cap] int32, 1 <= cap <= 64 (<= 128 for K > 4096): columns with p > 0 in no particular order, -1 in

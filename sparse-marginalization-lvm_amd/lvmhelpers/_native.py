@@ -98,7 +98,8 @@ SUPPORT_COLS_CAP_WIDE = 128   # rows wider than a wave's tile (K > 4096: 16 KB a
 
 def support_cols_cap(K):
     """List capacity the forward is asked for: a list stops paying near 45 entries at K <= 4096
-    (one 64-byte gather and one scattered store per entry against a 16 KB row), far later for the
+    (measured with the round-1 backward: one 64-byte gather and one scattered store per entry against
+    a 16 KB row; rows beyond it carry their pattern instead, which the backward compacts itself), far later for the
     segment backward of wider rows."""
     return SUPPORT_COLS_CAP if K <= 4096 else SUPPORT_COLS_CAP_WIDE
 
