@@ -391,6 +391,28 @@ def median_ms(fn, launches=20, warm=5):
     return t[launches // 2]
 
 
+def marginal_error(out, x, n, budget):
+    """Per sample: max_k |(M p)_k - mu*_k| against the closed-form marginals (Bernoulli:
+    clip((x+1)/2, 0, 1); budget: its projection onto sum mu <= budget, bisection on the multiplier),
+    from the fp32 distribution the kernel returns -- EVERY sample, whatever its exit status."""
+    k = torch.arange(n, device=x.device)
+    mu = torch.zeros(x.shape[0], n, dtype=torch.float64, device=x.device)
+    for c0 in range(0, out["p"].shape[1], 16):     # chunks of the active set: bounded temporaries
+        bits = ((out["aset_bits"][:, c0:c0 + 16, k // 32] >> (k % 32)) & 1).double()
+        mu += torch.einsum("bc,bcn->bn", out["p"][:, c0:c0 + 16].double(), bits)
+    a = (x.double() + 1) / 2
+    ref = a.clamp(0, 1)
+    if budget > 0:
+        lo = torch.zeros(x.shape[0], 1, dtype=torch.float64, device=x.device)
+        hi = a.max(-1, keepdim=True)[0].clamp(min=0)
+        for _ in range(100):
+            mid = (lo + hi) / 2
+            over = (a - mid).clamp(0, 1).sum(-1, keepdim=True) > budget
+            lo, hi = torch.where(over, mid, lo), torch.where(over, hi, mid)
+        ref = torch.where(ref.sum(-1, keepdim=True) <= budget, ref, (a - hi).clamp(0, 1))
+    return (mu - ref).abs().max(dim=-1)[0]
+
+
 def sparsemap_bench(native, dev, B, n, budget, sigma, reps=20, world=1, seed=77):
     g = torch.Generator(device=dev).manual_seed(seed)
     x = torch.randn(B, n, device=dev, generator=g) * sigma
@@ -401,10 +423,17 @@ def sparsemap_bench(native, dev, B, n, budget, sigma, reps=20, world=1, seed=77)
     dp = torch.randn(B, n + 1, device=dev, generator=g)
     bms = median_ms(lambda: native.sparsemap_bwd(dp, out["aset_bits"], out["alen"], out["inv_a"], n), reps, 2)
     iters = float(out["iters"].double().sum().item())
+    ok = out["status"] == 0
+    err = marginal_error(out, x, n, budget)
     res = {"B": B, "bits": n, "budget": budget, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
            "launches": reps, "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
-           "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
-           "converged_frac": float((out["status"] != 1).float().mean().item())}
+           "mean_iters": iters / B, "max_iters": int(out["iters"].max().item()),
+           "mean_support": float(out["alen"].float().mean().item()),
+           "converged_frac": float(ok.float().mean().item()),
+           "status_counts": torch.bincount(out["status"].long(), minlength=5).tolist(),
+           "max_marginal_err_all": float(err.max().item()),
+           "max_marginal_err_converged": float(err[ok].max().item()) if bool(ok.any()) else None,
+           "max_abs_sum_p_minus_1_all": float((out["p"].double().sum(-1) - 1).abs().max().item())}
     if _dist_on():  # whole-job figures: every rank solves its own B samples, slowest rank counts
         ms_max = max_over_ranks(ms, world, dev)
         res.update({"n_gpus": world, "B_total": B * world, "fwd_ms_max_over_ranks": ms_max,
@@ -428,7 +457,10 @@ def sparsemap_seq_bench(native, dev, B, n, sigma, reps=20, seed=77):
     return {"factor": "sequence_binary", "B": B, "positions": n, "sigma": sigma, "fwd_ms": ms, "bwd_ms": bms,
             "launches": reps, "samples_per_s": B / (ms * 1e-3), "active_set_iters_per_s": iters / (ms * 1e-3),
             "mean_iters": iters / B, "mean_support": float(out["alen"].float().mean().item()),
-            "converged_frac": float((out["status"] == 0).float().mean().item())}
+            "max_iters": int(out["iters"].max().item()),
+            "converged_frac": float((out["status"] == 0).float().mean().item()),
+            "status_counts": torch.bincount(out["status"].long(), minlength=5).tolist(),
+            "max_abs_sum_p_minus_1_all": float((out["p"].double().sum(-1) - 1).abs().max().item())}
 
 
 def compaction_bench(native, dev, R, K, sigma):

@@ -75,12 +75,57 @@
  *       convergences are artefacts of the drift); this restatement trades bit-for-bit imitation
  *       of that for results that can be certified: every CONVERGED sample has |sum p - 1| <= 1e-9
  *       (1e-12 in practice) and marginals within 1e-9 of the closed form.
+ *   C9  (round 3) C7 alone polishes at the END; but the drift also misleads the passes BEFORE a
+ *       would-be convergence: with a KKT residual of 1e-7 the solver inserts vertices whose gain is
+ *       noise, removes them again on a z_i = -1e-9 and never gets value - tau under 1e-9 -- the
+ *       1-4 % of 128-bit samples that ran to the pass limit in round 2 (traced here pass by pass:
+ *       tools/sm_trace.c; the residual grows by ~1.2x per update of the inverse, 1e-14 -> 1e-9 over
+ *       60 insertions, and a Gauss-Jordan rebuild of such a set is no more accurate than that).
+ *       What does recover the solution is iterative refinement on the EXACT residual (integers
+ *       times z).  So: after every solve that follows a change of the active set, sigma = sum_j z_j
+ *       (C1's sixty-four partials and tree) is compared with 1 -- row 0 of the KKT system, O(m) --
+ *       and once |1 - sigma| > SM_DRIFT_TOL (1e-11; the full residual is ~100x that) the sample
+ *       turns on POLISH mode for good: every later solve is followed by C7's sequence (residual;
+ *       up to SM_KKT_POLISH refinement steps while it exceeds SM_KKT_TOL; if that does not get
+ *       there, a rebuild -- C7's budget of SM_KKT_MAX_REBUILDS per sample, now 3 -- a new solve and
+ *       refinement).  A re-judgement (C7) turns it on as well.  Measured on the S5 grid (1024-8192
+ *       samples, 128 bits, sigma 0.3-3): 3-11 % of the samples switch, around pass 140-190; every
+ *       Bernoulli sample then converges within 200 passes.  What is left at the 300-pass limit is
+ *       slow convergence, not drift: ~1 % of the budget-64 samples and ~9 % of 128-position chains
+ *       zigzag across a face with a healthy residual and converge within ~800 passes.
+ *   C10 (round 3) In exact arithmetic a vertex that the oracle returns with value > tau is neither
+ *       active already nor an affine combination of the active ones (those all score tau).  When
+ *       either happens it is the residual speaking (value - tau = 1.001e-9 on a residual of 1e-9,
+ *       1.14e-9 on one of 9.8e-11 when the combination has large coefficients: 0.05-0.2 % of the
+ *       budget-64 samples at sigma = 3 left as SINGULAR that way): polish mode goes on, the
+ *       solution is polished with at least one refinement step whatever its residual, and the
+ *       next passes judge it again (blocking test, then optimality) -- once per active set (the
+ *       `judged` flag of C7).  Only on a solution judged that way do DUPLICATE and SINGULAR end
+ *       the sample.
+ *       Every polish (C7, C9, C10) that ends with a residual above SM_KKT_GIVEUP (1e-8, also NaN)
+ *       ends the sample as STALLED with its last feasible distribution: the refinement can diverge
+ *       on the nearly singular systems of the sequence factor once the rebuilds are spent, and its
+ *       z must reach neither the distribution nor a convergence decision.
+ *   C11 (round 3) the singularity test of C4 reads |s| <= 1e-6 (was 1e-9): s is a squared distance
+ *       between 0/1 points and an affine hull of 0/1 points -- zero or far above 1e-6 -- but it is
+ *       computed from the cached inverse, whose drift below C9's threshold already moves it by
+ *       ~1e-8 (a Bernoulli sample at sigma = 3 inserted a dependent vertex on s = -4.5e-9 and ended
+ *       with a singular system).  In polish mode, where the inverse is known to have drifted
+ *       further, d = invA r is refined by one step on the exact residual r - K d before s is
+ *       taken (d also fills the new row and column of the inverse, so the drift slows down).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
+/* per-pass trace for diagnosis (tools/sm_trace.c builds this file with -DSM_TRACE); a no-op otherwise */
+#ifdef SM_TRACE
+#include <stdio.h>
+#define SM_TR(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define SM_TR(...) ((void)0)
+#endif
 #define SM_MAX_N 512
 #define SM_WORDS(n) (((n) + 31) / 32)
 
@@ -227,7 +272,10 @@ static int common_values(const uint32_t* a, const uint32_t* b, int n)
 #define SM_KKT_PATIENCE 64     /* passes a re-judged sample gets to converge */
 #define SM_KKT_REJUDGE 1e-8   /* a starting residual above this voids the convergence decision */
 #define SM_KKT_POLISH 2       /* refinement steps per attempt */
-#define SM_KKT_MAX_REBUILDS 1 /* recomputations of the inverse per sample */
+#define SM_KKT_MAX_REBUILDS 3 /* recomputations of the inverse per sample (C7 and C9 together) */
+#define SM_KKT_GIVEUP 1e-8    /* a polish that ends above this cannot be judged: STALLED, last feasible p */
+#define SM_SINGULAR_TOL 1e-6  /* C11: |s| below this is a singular insertion */
+#define SM_DRIFT_TOL 1e-11    /* C9: |1 - sum z| above this turns polish mode on */
 
 /* C7: res[0..m] = [1; b] - K [tau; z] with K = [[0,1^T],[1,G]], G_ij = common values; every row
  * a serial left-to-right sum (product rounded, then added).  Returns max_i |res_i|. */
@@ -283,6 +331,73 @@ static void rebuild_inverse(double* A, int ld, const uint32_t* cfg, int m, int n
         }
         A[k * ld + k] = piv;
     }
+}
+
+/* [tau; z] (+)= invA^T rhs, one blocked sum (C1) per output */
+static void kkt_apply(const double* A, int ld, const double* rhs, int m, int accumulate, double* tau,
+                      double* z)
+{
+    for (int c = 0; c <= m; ++c) {
+        sum8_t acc8;
+        sum8_zero(&acc8);
+        for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * rhs[j]);
+        const double acc = sum8_get(&acc8);
+        if (c == 0) *tau = accumulate ? *tau + acc : acc;
+        else z[c - 1] = accumulate ? z[c - 1] + acc : acc;
+    }
+}
+
+/* C7 / C9: the polish sequence on the current solution.  res: m+1 doubles (holds the last
+ * residual), col/row: scratch for the rebuild.  Returns the residual it ends with; *rho0 gets the
+ * residual it started from. */
+static double kkt_polish(double* A, int ld, const uint32_t* cfg, int m, int n, const double* bvec,
+                         double* tau, double* z, double* res, double* col, double* row,
+                         int* rebuilds, double* rho0, int min_rounds)
+{
+    double rho = kkt_residual(z, *tau, bvec, cfg, m, n, res);
+    *rho0 = rho;
+    /* min_rounds = 1 (C10): one refinement step whatever the residual */
+    for (int round = 0; round < SM_KKT_POLISH && (rho > SM_KKT_TOL || round < min_rounds); ++round) {
+        kkt_apply(A, ld, res, m, 1, tau, z);   /* iterative refinement: [dtau; dz] = invA^T res */
+        rho = kkt_residual(z, *tau, bvec, cfg, m, n, res);
+    }
+    if (rho > SM_KKT_TOL && *rebuilds < SM_KKT_MAX_REBUILDS) {
+        /* the cached inverse is too far off for the refinement to converge */
+        rebuild_inverse(A, ld, cfg, m, n, col, row);
+        ++*rebuilds;
+        kkt_apply(A, ld, bvec, m, 0, tau, z);
+        rho = kkt_residual(z, *tau, bvec, cfg, m, n, res);
+        for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
+            kkt_apply(A, ld, res, m, 1, tau, z);
+            rho = kkt_residual(z, *tau, bvec, cfg, m, n, res);
+        }
+    }
+    return rho;
+}
+
+/* InvertAfterInsertion, first half (C4, C11): r = [1; common(cfg_i, newc)], d = invA r and, in
+ * polish mode, one step of iterative refinement of d on the exact residual r - K d (the residual
+ * of kkt_residual with [tau; z] = d and right-hand side r).  Returns s = n - r.d. */
+static double insertion_direction(const double* A, int ld, const uint32_t* cfg, const uint32_t* newc,
+                                  int m, int n, int polish, double* r, double* d, double* res)
+{
+    const int W = SM_WORDS(n);
+    r[0] = 1.0;
+    for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
+    for (int j = 0; j <= m; ++j) {
+        sum8_t acc8;
+        sum8_zero(&acc8);
+        for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; sum8_add(&acc8, i, A[i * ld + j] * r[i]); }
+        d[j] = sum8_get(&acc8);
+    }
+    if (polish) {
+        kkt_residual(d + 1, d[0], r, cfg, m, n, res);
+        kkt_apply(A, ld, res, m, 1, &d[0], d + 1);
+    }
+    sum64_t rd64;
+    sum64_zero(&rd64);
+    for (int j = 0; j <= m; ++j) sum64_add(&rd64, j, r[j] * d[j]);
+    return (double)n - sum64_get(&rd64);
 }
 
 /*
@@ -344,7 +459,7 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
         dist[0] = 1.0;
         A[0 * ld + 0] = -(double)n; A[0 * ld + 1] = 1.0; A[1 * ld + 0] = 1.0; A[1 * ld + 1] = 0.0;
 
-        int changed = 1, st = SM_MAXITER, it, judged = 0, refined = 0, rebuilds = 0, rejudges = 0, last_rejudge = 0;
+        int changed = 1, st = SM_MAXITER, it, judged = 0, refined = 0, rebuilds = 0, rejudges = 0, last_rejudge = 0, polish = 0, pending = 0;
         double tau = 0.0;
         for (it = 0; it < max_iter; ++it) {
             int same = 1;
@@ -353,14 +468,23 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                 bvec[0] = 1.0;
                 for (int i = 0; i < m; ++i) /* Evaluate under eta = [x; 0] (and the edge potentials) */
                     bvec[i + 1] = evaluate_cfg(cfg + i * W, eta, trans ? tr : NULL, n);
-                for (int c = 0; c <= m; ++c) {
-                    sum8_t acc8;
-                    sum8_zero(&acc8);
-                    for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * bvec[j]);
-                    const double acc = sum8_get(&acc8);
-                    if (c == 0) tau = acc; else z[c - 1] = acc;
+                kkt_apply(A, ld, bvec, m, 0, &tau, z);
+                if (!polish) { /* C9: drift monitor, row 0 of the KKT system */
+                    sum64_t sg;
+                    sum64_zero(&sg);
+                    for (int j = 0; j < m; ++j) sum64_add(&sg, j, z[j]);
+                    if (fabs(1.0 - sum64_get(&sg)) > SM_DRIFT_TOL) polish = 1;
                 }
                 same = 0;
+            }
+            if ((changed && polish) || pending) {
+                /* C9: every solve in polish mode; C10: the re-judgement asked for by the last pass
+                 * (one refinement step at least) */
+                double rho0;
+                const double rho = kkt_polish(A, ld, cfg, m, n, bvec, &tau, z, r, d, e_res, &rebuilds, &rho0, pending);
+                SM_TR("it %d m %d POLISH rho0 %.3e rho %.3e rebuilds %d pending %d\n", it, m, rho0, rho, rebuilds, pending);
+                if (!(rho <= SM_KKT_GIVEUP)) { st = SM_STALLED; break; }
+                if (pending) { refined = 1; pending = 0; }
             }
             if (refined) { refined = 0; same = 0; } /* C7: z was corrected in the last pass */
             if (same) {
@@ -371,43 +495,13 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                 for (int k = 0; k < n; ++k) { mu_on[k] = eta[k] - mu_on[k]; mu_off[k] = 0.0 - mu_off[k]; }
                 double value = trans ? maximize_seq(mu_on, mu_off, tr, n, newc, from0, from1)
                                      : maximize(mu_on, mu_off, n, budget, newc, e_tmp, idx_tmp);
+                SM_TR("it %d m %d ORACLE value-tau %.3e tau %.17g\n", it, m, value - tau, tau);
                 if (value <= tau + 1e-9) {
                     /* C7: accept only an accurate solution of the KKT system */
-                    const double rho0 = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                    double rho = rho0;
-                    for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
-                        for (int c = 0; c <= m; ++c) { /* [dtau; dz] = invA^T res */
-                            sum8_t acc8;
-                            sum8_zero(&acc8);
-                            for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * r[j]);
-                            const double acc = sum8_get(&acc8);
-                            if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
-                        }
-                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                    }
-                    if (rho > SM_KKT_TOL && rebuilds < SM_KKT_MAX_REBUILDS) {
-                        /* the cached inverse is too far off for the refinement to converge */
-                        rebuild_inverse(A, ld, cfg, m, n, d, e_res);
-                        ++rebuilds;
-                        for (int c = 0; c <= m; ++c) {
-                            sum8_t acc8;
-                            sum8_zero(&acc8);
-                            for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * bvec[j]);
-                            const double acc = sum8_get(&acc8);
-                            if (c == 0) tau = acc; else z[c - 1] = acc;
-                        }
-                        rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                        for (int round = 0; round < SM_KKT_POLISH && rho > SM_KKT_TOL; ++round) {
-                            for (int c = 0; c <= m; ++c) {
-                                sum8_t acc8;
-                                sum8_zero(&acc8);
-                                for (int j = 0; j <= m; ++j) sum8_add(&acc8, j, A[j * ld + c] * r[j]);
-                                const double acc = sum8_get(&acc8);
-                                if (c == 0) tau = tau + acc; else z[c - 1] = z[c - 1] + acc;
-                            }
-                            rho = kkt_residual(z, tau, bvec, cfg, m, n, r);
-                        }
-                    }
+                    double rho0;
+                    const double rho = kkt_polish(A, ld, cfg, m, n, bvec, &tau, z, r, d, e_res, &rebuilds, &rho0, 0);
+                    SM_TR("it %d C7 rho0 %.3e rho %.3e rebuilds %d\n", it, rho0, rho, rebuilds);
+                    if (!(rho <= SM_KKT_GIVEUP)) { st = SM_STALLED; break; }
                     if (rho0 > SM_KKT_REJUDGE && !judged) {
                         if (rejudges >= SM_KKT_MAX_REJUDGES) { st = SM_STALLED; break; }
                         ++rejudges;
@@ -416,6 +510,7 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                          * passes judge the polished one (blocking test, then optimality) */
                         judged = 1;
                         refined = 1;
+                        polish = 1; /* C9 */
                         continue;
                     }
                     for (int i = 0; i < m; ++i) dist[i] = z[i];
@@ -424,26 +519,32 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                 }
                 int dup = 0;
                 for (int i = 0; i < m && !dup; ++i) dup = (memcmp(cfg + i * W, newc, sizeof(uint32_t) * W) == 0);
-                if (dup) { st = SM_DUPLICATE; break; }
+                if (dup) {
+                    if (judged) { st = SM_DUPLICATE; break; }
+                    /* C10: polish the solution (one refinement step at least) and judge again */
+                    polish = 1;
+                    judged = 1;
+                    pending = 1;   /* polished at the top of the next pass */
+                    SM_TR("it %d m %d C10 duplicate\n", it, m);
+                    continue;
+                }
                 if (m >= cap && !trans) { st = SM_SINGULAR; break; } /* n+1 affinely independent vertices at most (C8 swaps) */
                 z[m] = 0.0;
                 for (int i = 0; i <= m; ++i) dist[i] = z[i];
                 /* InvertAfterInsertion */
-                r[0] = 1.0;
-                for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
-                for (int j = 0; j <= m; ++j) {
-                    sum8_t acc8;
-                    sum8_zero(&acc8);
-                    for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; sum8_add(&acc8, i, A[i * ld + j] * r[i]); }
-                    d[j] = sum8_get(&acc8);
-                }
-                sum64_t rd64;
-                sum64_zero(&rd64);
-                for (int j = 0; j <= m; ++j) sum64_add(&rd64, j, r[j] * d[j]);
-                double s = (double)n - sum64_get(&rd64);
+                double s = insertion_direction(A, ld, cfg, newc, m, n, polish, r, d, e_res);
+                SM_TR("it %d INSERT at %d s %.3e newc %08x%08x%08x%08x\n", it, m, s, newc[0], W > 1 ? newc[1] : 0, W > 2 ? newc[2] : 0, W > 3 ? newc[3] : 0);
                 double w_new = 0.0;   /* weight the new vertex starts with */
-                if (s <= 1e-9 && s >= -1e-9) {
-                    if (!trans) { st = SM_SINGULAR; break; }
+                if (s <= SM_SINGULAR_TOL && s >= -SM_SINGULAR_TOL) {
+                    if (!trans) {
+                        if (judged) { st = SM_SINGULAR; break; }
+                        /* C10: see the header */
+                        polish = 1;
+                        judged = 1;
+                        pending = 1;
+                        SM_TR("it %d m %d C10 singular\n", it, m);
+                        continue;
+                    }
                     /* C8 (sequence factor only): the new vertex is an affine combination of the
                      * active ones in variable space, y_new = sum_i c_i y_i with c = d[1..m] (d
                      * solves the KKT system for r).  Its score is higher than the same combination
@@ -486,18 +587,8 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                         --m;
                     }
                     /* the insertion again, on the reduced set */
-                    r[0] = 1.0;
-                    for (int i = 0; i < m; ++i) r[i + 1] = (double)common_values(cfg + i * W, newc, n);
-                    for (int j = 0; j <= m; ++j) {
-                        sum8_t acc8;
-                        sum8_zero(&acc8);
-                        for (int i = 0; i <= m; ++i) { if (r[i] == 0.0) continue; sum8_add(&acc8, i, A[i * ld + j] * r[i]); }
-                        d[j] = sum8_get(&acc8);
-                    }
-                    sum64_zero(&rd64);
-                    for (int j = 0; j <= m; ++j) sum64_add(&rd64, j, r[j] * d[j]);
-                    s = (double)n - sum64_get(&rd64);
-                    if (s <= 1e-9 && s >= -1e-9) { st = SM_SINGULAR; break; }
+                    s = insertion_direction(A, ld, cfg, newc, m, n, polish, r, d, e_res);
+                    if (s <= SM_SINGULAR_TOL && s >= -SM_SINGULAR_TOL) { st = SM_SINGULAR; break; }
                     w_new = theta;
                 } else if (m >= cap) { /* a full set that rounding calls independent: no room */
                     st = SM_SINGULAR;
@@ -527,10 +618,12 @@ static int sparsemap_fwd_impl(const float* scores, const float* trans, const dou
                     if (blocking < 0 || tmp < alpha) { alpha = tmp; blocking = i; }
                 }
                 if (!exist) {
+                    SM_TR("it %d m %d FULLSTEP\n", it, m);
                     for (int i = 0; i < m; ++i) dist[i] = z[i];
                     changed = 0;
                 } else {
                     if (alpha > 1.0) alpha = 1.0;
+                    SM_TR("it %d m %d REMOVE %d alpha %.3e z %.3e dist %.3e cfg %08x%08x%08x%08x\n", it, m, blocking, alpha, z[blocking], dist[blocking], cfg[blocking * W], W > 1 ? cfg[blocking * W + 1] : 0, W > 2 ? cfg[blocking * W + 2] : 0, W > 3 ? cfg[blocking * W + 3] : 0);
                     if (alpha == 1.0) {
                         for (int i = 0; i < m; ++i) dist[i] = z[i];
                     } else {

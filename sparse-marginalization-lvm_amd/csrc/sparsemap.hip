@@ -6,8 +6,9 @@
 // oracles of lvmhelpers/bernoulli.h:14-35 (Bernoulli) and lvmhelpers/budget.h:24-85 (budget), and
 // lvmhelpers/sparsemap.py:38-44 (dist_jacobian_vec) for the backward.
 //
-// The arithmetic follows oracle/sparsemap_oracle.c choice by choice (C1..C8 there) so that the
-// active set -- which is path dependent -- comes out identical: every fp64 sum that feeds a
+// The arithmetic follows oracle/sparsemap_oracle.c choice by choice (C1..C9 there) so that the
+// active set -- which is path dependent -- comes out identical (C9, round 3: the drift monitor and
+// polish mode, is in kkt_polish and at the solve of the main loop): every fp64 sum that feeds a
 // decision adds the same numbers in the oracle's order (C1: the long sums as eight interleaved
 // partial sums combined pairwise, the marginals and residual rows left to right), owned by ONE
 // lane per output (lane c owns output c; sums that produce a single scalar are accumulated
@@ -526,7 +527,10 @@ struct Sm {
 constexpr double kKktTol = 1e-10;      // accepted residual (any row)
 constexpr double kKktRejudge = 1e-8;   // a starting residual above this voids the convergence decision
 constexpr int kKktPolish = 2;          // refinement steps per attempt
-constexpr int kKktMaxRebuilds = 1;     // recomputations of the inverse per sample
+constexpr int kKktMaxRebuilds = 3;     // recomputations of the inverse per sample (C7 and C9 together)
+constexpr double kKktGiveUp = 1e-8;    // a polish that ends above this cannot be judged: STALLED
+constexpr double kSingularTol = 1e-6;  // C11: |s| below this is a singular insertion
+constexpr double kDriftTol = 1e-11;    // C9: |1 - sum z| above this turns polish mode on
 constexpr int kKktMaxRejudges = 2;     // re-judgements per sample
 constexpr int kKktPatience = 64;       // passes a re-judged sample gets to converge
 
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     }
     wsync();
     int m = 1, it = 0, rebuilds = 0, rejudges = 0, last_rejudge = 0;
-    bool changed = true;
+    bool changed = true, polish = false;   // polish: C9, sticky
     double tau = 0.0;
     if (!resume) {
         double value, evalsum;
@@ -731,6 +735,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     } else {
         m = uni(alen[s]);
         it = uni(ws_it[s]);
+        polish = uni((ws_state[s] >> 1) & 1) != 0;
         rebuilds = uni((ws_state[s] >> 4) & 15);
         rejudges = uni((ws_state[s] >> 8) & 15);
         last_rejudge = uni(ws_state[s] >> 12);
@@ -754,11 +759,13 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
     SM_T0();
     int st = SM_MAXITER;
     bool overflow = false;
-    // C7: judged / refined are never set when a sample is parked (that happens in an insertion
-    // pass, which clears them); the rebuild / re-judgement counts travel in ws_state
-    bool judged = false, refined = false;
+    // refined / pending are never set when a sample is parked (that happens in an insertion pass,
+    // after they were consumed); judged, polish and the rebuild / re-judgement counts travel in
+    // ws_state
+    bool judged = false, refined = false, pending = false;
+    if (resume) judged = uni((ws_state[s] >> 2) & 1) != 0;
     // [tau; z] (+)= invA^T rhs: lane c owns output c, blocked over j like the oracle (C1)
-    auto kkt_apply = [&](const double* rhs, bool accumulate) {
+    auto kkt_apply = [&](const double* rhs, bool accumulate) __attribute__((always_inline)) {
         const int cnt8 = round8(m + 1);
         double t0 = 0.0;
         double mv[(L::NA + 63) / 64];
@@ -778,8 +785,33 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         tau = accumulate ? uni(tau + t0) : uni(t0);
         wsync();
     };
+    // C7 / C9: the polish sequence on the current solution (the oracle's kkt_polish): residual, up
+    // to kKktPolish refinement steps, a rebuild if that does not get there; returns the residual it
+    // ends with (rho0: the one it started from).  Uses r (residual), d and t1 (rebuild scratch):
+    // free outside an insertion.
+    auto kkt_polish = [&](double& rho0, int min_rounds) __attribute__((always_inline)) -> double {
+        rho0 = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+        double rho = rho0;
+        // min_rounds = 1 (C10): one refinement step whatever the residual
+        for (int round = 0; round < kKktPolish && (rho > kKktTol || round < min_rounds); ++round) {
+            kkt_apply(r, true);   // iterative refinement: [dtau; dz] = invA^T res
+            rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+        }
+        if (rho > kKktTol && rebuilds < kKktMaxRebuilds) {
+            // the cached inverse is too far off for the refinement to converge
+            rebuild_inverse<LD, WT>(A, cfg, m, n, d, t1, lane);
+            ++rebuilds;
+            kkt_apply(bsc, false);
+            rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+            for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
+                kkt_apply(r, true);
+                rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
+            }
+        }
+        return rho;
+    };
     // InvertAfterRemoval(idx) and erase entry idx of the active set (m decreases by one)
-    auto remove_entry = [&](int idx) {
+    auto remove_entry = [&](int idx) __attribute__((always_inline)) {
         // InvertAfterRemoval
         const int ri = idx + 1;
         wsync();
@@ -852,7 +884,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         --m;
     };
     // r = [1; CountCommonValues(cfg_i, new)]; true if the new configuration is already active
-    auto common_with_new = [&]() -> bool {
+    auto common_with_new = [&]() __attribute__((always_inline)) -> bool {
         bool dup = false;
 #pragma unroll
         for (int q = 0; q * 64 < L::NA; ++q) {
@@ -872,22 +904,51 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         }
         return __any(dup) != 0;
     };
-    // d = invA r (zero beyond m), prod = r .* d; returns s = n - sum_j r_j d_j
-    auto insertion_direction = [&]() -> double {
+    // d = invA r (zero beyond m) -- in polish mode refined by one step on the exact residual
+    // r - K d (C11) --; returns s = n - sum_j r_j d_j
+    auto insertion_direction = [&]() __attribute__((always_inline)) -> double {
         wsync();
         const int cnt8 = round8(m + 1);
         double mv[(L::NA + 63) / 64];
+        double dl[(L::NA + 63) / 64];
         matvec_chunks<LD, L::NA>(A, r, cnt8, lane, mv);
+#pragma unroll
+        for (int q = 0; q * 64 < L::NA; ++q) {
+            const int j = lane + 64 * q;
+            dl[q] = 0.0;
+            if (q * 64 <= cnt8 && j < L::NA) {
+                dl[q] = (j <= m) ? mv[q] : 0.0;
+                d[j] = dl[q];
+            }
+        }
+        if (polish) {
+            // the residual of kkt_residual with [tau; z] = d and right-hand side r; z = d[1..] is
+            // copied to an aligned, zero-padded vector (prod), the residual goes to t1
+            double* zz = S.prod();
+            wsync();
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int j = lane + 64 * q;
+                if (q * 64 <= cnt8 && j < L::NA) zz[j] = (j < m) ? d[j + 1] : 0.0;
+            }
+            const double d0 = uni(d[0]);
+            wsync();
+            kkt_residual<WT, L::NA>(zz, d0, r, cfg, m, n, t1, lane);
+            matvec_chunks<LD, L::NA>(A, t1, cnt8, lane, mv);
+#pragma unroll
+            for (int q = 0; q * 64 < L::NA; ++q) {
+                const int j = lane + 64 * q;
+                if (q * 64 <= cnt8 && j < L::NA && j <= m) {
+                    dl[q] = dl[q] + mv[q];
+                    d[j] = dl[q];
+                }
+            }
+        }
         double prd = 0.0;
 #pragma unroll
         for (int q = 0; q * 64 < L::NA; ++q) {
             const int j = lane + 64 * q;
-            if (q * 64 <= cnt8 && j < L::NA) {
-                const double acc = mv[q];
-                const double dj = (j <= m) ? acc : 0.0;
-                d[j] = dj;
-                prd += r[j] * dj;   // r is 0 beyond m
-            }
+            if (q * 64 <= cnt8 && j < L::NA) prd += r[j] * dl[q];   // r is 0 beyond m
         }
         wsync();
         SM_T(4);
@@ -900,8 +961,25 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         if (changed) {
             // [tau; z] = invA^T b, b = [1; Evaluate(cfg_i)]
             kkt_apply(bsc, false);
-            same = false;
+            if (!polish) {   // C9: drift monitor, row 0 of the KKT system; term j -> partial j mod 64
+                double pz = 0.0;
+#pragma unroll
+                for (int q = 0; q * 64 < L::NA; ++q)
+                    if (q * 64 < m && lane + 64 * q < L::NA) pz += z[lane + 64 * q];   // zero beyond m
+                polish = uni(fabs(1.0 - wave_sum(pz)) > kDriftTol);
+            }
             SM_T(0);
+            same = false;
+        }
+        if ((changed && polish) || pending) {
+            // C9: every solve in polish mode; C10: the re-judgement asked for by the last pass (one
+            // refinement step at least).  A polish that ends above kKktGiveUp (or NaN) cannot be
+            // judged: STALLED, last feasible p.
+            double rho0;
+            const bool failed = !uni(kkt_polish(rho0, pending ? 1 : 0) <= kKktGiveUp);
+            SM_T(7);
+            if (failed) { st = SM_STALLED; break; }
+            if (pending) { refined = true; pending = false; }
         }
         if (refined) { refined = false; same = false; }   // C7: z was re-solved in the last pass
         if (same) {
@@ -919,23 +997,8 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             SM_T(2);
             if (uni(value <= tau + 1e-9)) {
                 // C7: accept only an accurate solution of the KKT system
-                const double rho0 = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                double rho = rho0;
-                for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
-                    kkt_apply(r, true);   // iterative refinement: [dtau; dz] = invA^T res
-                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                }
-                if (rho > kKktTol && rebuilds < kKktMaxRebuilds) {
-                    // the cached inverse is too far off for the refinement to converge
-                    rebuild_inverse<LD, WT>(A, cfg, m, n, d, t1, lane);
-                    ++rebuilds;
-                    kkt_apply(bsc, false);
-                    rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                    for (int round = 0; round < kKktPolish && rho > kKktTol; ++round) {
-                        kkt_apply(r, true);
-                        rho = kkt_residual<WT, L::NA>(z, tau, bsc, cfg, m, n, r, lane);
-                    }
-                }
+                double rho0;
+                if (!uni(kkt_polish(rho0, 0) <= kKktGiveUp)) { st = SM_STALLED; break; }
                 if (rho0 > kKktRejudge && !judged) {
                     // the solution moved by more than the convergence tolerance: the next passes
                     // judge the polished one (blocking test, then optimality)
@@ -944,6 +1007,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                     last_rejudge = it;
                     judged = true;
                     refined = true;
+                    polish = true;   // C9
                     SM_T(7);
                     continue;
                 }
@@ -954,7 +1018,14 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 break;
             }
             // SameConfiguration against every active entry + r = [1; CountCommonValues(cfg_i, new)]
-            if (common_with_new()) { st = SM_DUPLICATE; break; }
+            if (common_with_new()) {
+                if (judged) { st = SM_DUPLICATE; break; }
+                // C10: polish the solution (one refinement step at least) and judge again
+                polish = true;
+                judged = true;
+                pending = true;   // polished at the top of the next pass
+                continue;
+            }
             if constexpr (!SEQ) {
                 if (m >= cap) { st = SM_SINGULAR; break; }
                 if (m + 2 > LD) { overflow = true; break; }   // next tier redoes this pass
@@ -970,8 +1041,15 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
             // InvertAfterInsertion: d = invA r, s = n - r.d
             double sden = insertion_direction();
             double w_new = 0.0;   // weight the new vertex starts with
-            if (uni(sden <= 1e-9 && sden >= -1e-9)) {
-                if constexpr (!SEQ) { st = SM_SINGULAR; break; }
+            if (uni(sden <= kSingularTol && sden >= -kSingularTol)) {
+                if constexpr (!SEQ) {
+                    if (judged) { st = SM_SINGULAR; break; }
+                    // C10 (see the oracle's header)
+                    polish = true;
+                    judged = true;
+                    pending = true;
+                    continue;
+                }
                 // C8 (sequence factor only): the new vertex is an affine combination of the active
                 // ones in variable space, y_new = sum_i c_i y_i with c = d[1..m].  Its score is
                 // higher than the same combination of theirs, so weight moves onto it along
@@ -1000,7 +1078,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
                 // the insertion again, on the reduced set
                 common_with_new();
                 sden = insertion_direction();
-                if (uni(sden <= 1e-9 && sden >= -1e-9)) { st = SM_SINGULAR; break; }
+                if (uni(sden <= kSingularTol && sden >= -kSingularTol)) { st = SM_SINGULAR; break; }
                 w_new = theta;
             } else if constexpr (SEQ) {
                 if (m >= cap) { st = SM_SINGULAR; break; }   // a full set that rounding calls independent
@@ -1136,7 +1214,7 @@ __global__ __launch_bounds__(64) void sparsemap_fwd_kernel(
         if (iters) iters[s] = it;
         if (status) status[s] = st;
         if (ws_state) {
-            ws_state[s] = overflow ? (1 | (rebuilds << 4) | (rejudges << 8) | (last_rejudge << 12)) : 0;
+            ws_state[s] = overflow ? (1 | ((int)polish << 1) | ((int)judged << 2) | (rebuilds << 4) | (rejudges << 8) | (last_rejudge << 12)) : 0;
             ws_it[s] = it;
             ws_tau[s] = tau;
         }

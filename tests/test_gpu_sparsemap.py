@@ -58,7 +58,7 @@ def test_fwd_bwd_match_oracle(dev, oracle_mod, B, n, sigma, budget, use_init, ki
     np.testing.assert_allclose(d, d_ref, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(d_ref).max()))
 
 
-@pytest.mark.parametrize("sigma,budget", [(1.0, 0), (0.7, 64), (1.0, 100)])
+@pytest.mark.parametrize("sigma,budget", [(1.0, 0), (0.3, 64), (1.0, 100)])
 def test_tiers_resume_bit_identical(dev, oracle_mod, sigma, budget):
     """n > 64 runs in LDS tiers (storage for 63, 93, 129 active vertices); samples that outgrow a
     tier are parked and resumed by the next launch.  192 samples at 128 bits reach every tier (the
@@ -108,6 +108,37 @@ def test_oversubscribed_batch_starts_in_the_small_tier(dev, oracle_mod):
         assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
 
 
+@pytest.mark.parametrize("sigma,budget,seq", [(1.0, 0, False), (3.0, 64, False), (1.0, 64, False),
+                                              (3.0, 0, False), (1.0, 0, True)])
+def test_polish_mode_paths_match_oracle(dev, oracle_mod, sigma, budget, seq):
+    """C9-C11 of the oracle (drift monitor, polish mode, re-judged duplicate / singular insertions,
+    refined insertion direction) only act on a few % of 128-bit samples, late in their runs: 768
+    samples per case, enough for every path to be taken, bit for bit against the CPU oracle."""
+    from lvmhelpers import _native
+    B, n = 768, 128
+    x, init = _inputs(B, n, sigma, 31337 + budget)
+    xd, initd = torch.from_numpy(x).to(dev), torch.from_numpy(init).to(dev)
+    if seq:
+        t = (sigma * np.random.default_rng(5).standard_normal((B, n - 1))).astype(np.float32)
+        ref = oracle_mod.sparsemap_seq_fwd(x, t, init, 300)
+        out = _native.sparsemap_seq_fwd(xd, torch.from_numpy(t).to(dev), initd, 300)
+    else:
+        ref = oracle_mod.sparsemap_fwd(x, init, budget, 300)
+        out = _native.sparsemap_fwd(xd, initd, budget, 300)
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
+    alen = out["alen"].cpu().numpy()
+    assert np.array_equal(alen, ref["alen"])
+    assert np.array_equal(out["aset_bits"].cpu().numpy().view(np.uint32), ref["aset_bits"])
+    assert np.array_equal(out["p"].cpu().numpy(), ref["p"])
+    inv = out["inv_a"].cpu().numpy()
+    for b in range(0, B, 3):
+        m = alen[b]
+        assert np.array_equal(inv[b, :m + 1, :m + 1], ref["invA"][b, :m + 1, :m + 1])
+    # nothing but feasible distributions leaves the solver, whatever the status
+    assert np.abs(ref["p64"].sum(-1) - 1).max() <= 1e-9 and ref["p64"].min() >= 0.0
+
+
 def test_max_iter_is_respected(dev, oracle_mod):
     from lvmhelpers import _native
     x, init = _inputs(8, 64, 1.0, 9)
@@ -119,31 +150,45 @@ def test_max_iter_is_respected(dev, oracle_mod):
         assert np.array_equal(out["iters"].cpu().numpy(), ref["iters"])
 
 
-@pytest.mark.parametrize("sigma,budget", [(3.0, 0), (1.0, 0), (3.0, 64)])
-def test_marginals_closed_form_full_size(dev, oracle_mod, sigma, budget):
-    """cfg5 shape (1024 samples/GPU at 128 bits): for EVERY converged sample M p equals the
-    closed-form marginals and sum p = 1 to the precision of the fp32 output (1e-6) -- the solver
-    only accepts a convergence on an accurate solution of the KKT system (C7 of the oracle:
-    residual check, inverse rebuilt from the active set when it has drifted, iterative refinement).
+# Stated bound on the marginals of a sample that leaves at the pass limit (status MAXITER): its
+# distribution is the last feasible iterate of a descent method, measured at <= 2.4e-3 from the
+# optimum on these inputs (oracle, round 3); 2e-2 is asserted.
+MAXITER_MARGINAL_BOUND = 2e-2
+
+
+@pytest.mark.parametrize("B,sigma,budget", [(1024, 3.0, 0), (1024, 1.0, 0), (1024, 0.3, 0), (1024, 3.0, 64),
+                                            (1024, 1.0, 64), (8192, 1.0, 0)])
+def test_marginals_closed_form_full_size(dev, oracle_mod, B, sigma, budget):
+    """cfg5 shape (1024 samples/GPU at 128 bits, and the whole 8192 batch): EVERY sample -- no filter
+    on the exit status -- has p >= 0 and sum p = 1, and M p equals the closed-form marginals to the
+    precision of the fp32 output (1e-6) unless the sample left at the pass limit, where the stated
+    bound above holds.  Bernoulli factor: every sample converges (C9 of the oracle: drift monitor +
+    polish mode; round 2 left 1-4 % at the limit).  Budget factor: >= 98 % converge within the
+    reference's 300 passes (structmarg.py:165), the rest is slow convergence with a healthy KKT
+    residual (they converge within ~800 passes, tests/test_oracle_sparsemap.py).
     A slice of the batch is compared with the fp64 oracle bit for bit, where the same holds to 1e-9."""
     from lvmhelpers import _native
-    B, n = 1024, 128
+    n = 128
     g = torch.Generator(device=dev).manual_seed(1)
     x = torch.randn(B, n, device=dev, generator=g) * sigma
     init = torch.rand(B, 2 * n, dtype=torch.double, generator=torch.Generator().manual_seed(3)).to(dev)
     out = _native.sparsemap_fwd(x, init, budget, 300)
     ok = out["status"] == 0  # converged by the KKT test (value <= tau + 1e-9) on an accurate solution
-    assert ok.float().mean() > 0.8
+    late = out["status"] == 1
+    assert bool((ok | late).all()), "only CONVERGED / MAXITER are expected on these inputs"
+    if budget == 0:
+        assert bool(ok.all()), f"{int((~ok).sum())} Bernoulli samples did not converge"
+    else:
+        assert ok.float().mean() >= 0.98
     k = torch.arange(n, device=dev)
     bits = ((out["aset_bits"][..., k // 32] >> (k % 32)) & 1).double()     # [B,cap,n]
     mu = torch.einsum("bc,bcn->bn", out["p"].double(), bits)
     psum = (out["p"].double().sum(-1) - 1).abs()
-    assert float(psum[ok].max()) <= 1e-6
-    assert bool((out["p"][ok] >= 0).all()) or float(out["p"][ok].min()) > -1e-9
+    assert float(psum.max()) <= 1e-6                      # every sample
+    assert float(out["p"].min()) >= 0.0                  # every sample
+    assert bool((out["alen"] >= 1).all())
     if budget == 0:
         mu_ref = ((x.double() + 1) / 2).clamp(0, 1)
-        err = (mu - mu_ref).abs().max(dim=-1)[0]
-        assert float(err[ok].max()) <= 1e-6
     else:
         assert bool((bits.sum(-1)[out["p"] > 0] <= budget).all())
         # the marginals are the projection of (x+1)/2 onto {0 <= mu <= 1, sum mu <= budget}
@@ -156,7 +201,10 @@ def test_marginals_closed_form_full_size(dev, oracle_mod, sigma, budget):
             lo, hi = torch.where(over, mid, lo), torch.where(over, hi, mid)
         free = a.clamp(0, 1).sum(-1, keepdim=True) <= budget
         mu_ref = torch.where(free, a.clamp(0, 1), (a - hi).clamp(0, 1))
-        assert float((mu - mu_ref).abs().max(dim=-1)[0][ok].max()) <= 1e-6
+    err = (mu - mu_ref).abs().max(dim=-1)[0]
+    assert float(err[ok].max()) <= 1e-6
+    if bool(late.any()):
+        assert float(err[late].max()) <= MAXITER_MARGINAL_BOUND
     # the first 96 samples against the oracle: identical, and accurate to 1e-9 in fp64 there
     nb = 96
     ref = oracle_mod.sparsemap_fwd(x[:nb].cpu().numpy(), init[:nb].cpu().numpy(), budget, 300)

@@ -75,8 +75,7 @@ def test_config5_step_at_the_per_gpu_batch(dev):
     assert bool((idx[1:] >= idx[:-1]).all()) and int(idx[0]) == 0 and int(idx[-1]) == 1023
     assert torch.equal(torch.bincount(idx, minlength=1024).float().cpu(), lg["support"].cpu())
     sums = torch.zeros(1024, device=dev, dtype=torch.float64).index_add_(0, idx, lg["distr"].double())
-    assert float((sums - 1).abs().max()) <= 1e-3          # see DESIGN section 4 on near-singular insertions
-    assert float((sums - 1).abs().median()) <= 1e-6
+    assert float((sums - 1).abs().max()) <= 1e-6          # every sample: the fp32 precision of p
     assert bool((lg["distr"] > 0).all())
     for p in model.parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all())

@@ -101,6 +101,45 @@ def test_every_converged_sample_is_accurate_at_128_bits(sigma, budget):
         assert np.abs(o["invA"][b, :m + 1, :m + 1] @ A - np.eye(m + 1)).max() < 5e-3
 
 
+@pytest.mark.parametrize("sigma", [0.3, 1.0, 3.0])
+def test_every_bernoulli_sample_converges_at_128_bits(sigma):
+    """C9 of the oracle (drift monitor + polish mode): in round 2, 1-4 % of the 128-bit samples ran
+    to the 300-pass limit because the drifted inverse (KKT residual ~1e-7) kept inserting and
+    removing noise vertices.  Now EVERY sample converges, well inside the limit, with the
+    closed-form marginals and sum p = 1 to 1e-9 -- no filter on the status."""
+    B, n = 1024, 128
+    x, init = _problem(B, n, sigma, 1234)
+    o = oracle.sparsemap_fwd(x, init, 0, 300)
+    assert np.all(o["status"] == 0)
+    assert o["iters"].max() <= 220
+    assert np.abs(o["p64"].sum(-1) - 1).max() <= 1e-9
+    assert o["p64"].min() >= 0.0
+    mu, _ = _marginals(o, n)
+    assert np.abs(mu - np.clip((x.astype(np.float64) + 1) / 2, 0, 1)).max() <= 1e-9
+
+
+def test_budget_samples_at_the_pass_limit_are_slow_not_stuck():
+    """What is left at the reference's 300-pass limit (structmarg.py:165) with a budget of 64 on
+    sigma = 1 scores is slow convergence: every sample is feasible (sum p = 1, p >= 0, budget kept),
+    the ones that hit the limit are within a stated bound of the optimal marginals, and the same
+    inputs all converge when given 1000 passes."""
+    B, n, budget = 512, 128, 64
+    x, init = _problem(B, n, 1.0, 99)
+    o = oracle.sparsemap_fwd(x, init, budget, 300)
+    ok, late = o["status"] == 0, o["status"] == 1
+    assert np.all(ok | late) and ok.mean() >= 0.98
+    assert np.abs(o["p64"].sum(-1) - 1).max() <= 1e-9 and o["p64"].min() >= 0.0
+    mu, bits = _marginals(o, n)
+    ref = _budget_projection(x, budget)
+    err = np.abs(mu - ref).max(-1)
+    assert err[ok].max() <= 1e-7
+    assert err.max() <= 2e-2                     # the stated bound for MAXITER samples
+    o2 = oracle.sparsemap_fwd(x, init, budget, 1000)
+    assert np.all(o2["status"] == 0)
+    mu2, _ = _marginals(o2, n)
+    assert np.abs(mu2 - ref).max() <= 1e-7
+
+
 def test_vertex_solution_without_init():                                                    # (vi)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((16, 24)).astype(np.float32)
