@@ -471,13 +471,19 @@ def compaction_bench(native, dev, R, K, sigma):
     8(R+1) + one 64-byte sector per gathered probability; reduce 8N read of vals and comps)."""
     import ctypes
     x, _ = gen(R, K, sigma, dev, 4321)
-    p, supp, nnz, _, _, lists = native.sparsemax_fwd(x, want_nnz=True, want_cols=True)
-    del x
+    p, supp, nnz, _, _, lists, vlists = native.sparsemax_fwd(x, want_nnz=True, want_cols=True, want_vals=True)
     L = native.lib()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
     cap = lists.shape[1]
     i64, i32 = ctypes.c_int64, ctypes.c_int32
+    # what the value lists cost the forward (same launch with and without them)
+    mb = L.smlvm_sparsemax_support_mask_bytes(i64(R), i32(K))
+    mask = torch.zeros(max(mb // 4, 1), dtype=torch.int32, device=dev)
+    fw = lambda vl: (lambda: L.smlvm_sparsemax_fwd_lists(P(x), P(p), P(supp), None, None, None, P(lists), P(vl),
+                                                          i32(cap), P(mask) if mb else None, i64(R), i32(K), st))
+    t_fwd_cols, t_fwd_lists = median_ms(fw(None)), median_ms(fw(vlists))
+    del x
     off = torch.empty(R + 1, dtype=torch.int64, device=dev)
     ws_b = L.smlvm_support_offsets_workspace_bytes(i64(R))
     ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
@@ -495,6 +501,19 @@ def compaction_bench(native, dev, R, K, sigma):
     vals = torch.empty(N, dtype=torch.float32, device=dev)
     t_comp = median_ms(lambda: ok(L.smlvm_support_compact(P(p), P(off), P(rows), P(cols), P(vals), i64(R), i32(K), st)))
     t_comp_l = median_ms(lambda: ok(L.smlvm_support_compact_cols(P(p), P(lists), i32(cap), P(off), P(rows), P(cols), P(vals), i64(R), i32(K), st)))
+    # the single pass: count + look-back scan + compaction in one launch, entries sized by R * cap
+    ncap = R * cap
+    f_rows = torch.empty(ncap, dtype=torch.int32, device=dev)
+    f_cols = torch.empty(ncap, dtype=torch.int32, device=dev)
+    f_vals = torch.empty(ncap, dtype=torch.float32, device=dev)
+    fb = L.smlvm_support_compact_fused_workspace_bytes(i64(R))
+    fws = torch.empty(fb // 8, dtype=torch.int64, device=dev)
+    fused = lambda vl: (lambda: ok(L.smlvm_support_compact_fused(P(p), P(lists), P(vl), i32(cap), P(off), P(f_rows),
+                                                                  P(f_cols), P(f_vals), i64(ncap), i64(R), i32(K),
+                                                                  P(fws), ctypes.c_size_t(fb), st)))
+    t_fused, t_fused_v = median_ms(fused(None)), median_ms(fused(vlists))
+    assert int(fws[2].item()) == N and int(fws[1].item()) == 0
+    del f_rows, f_cols, f_vals
     comps = torch.rand(N, device=dev) * 500
     total = torch.empty(1, dtype=torch.float32, device=dev)
     wr_b = L.smlvm_weighted_loss_reduce_workspace_bytes(i64(N))
@@ -503,7 +522,8 @@ def compaction_bench(native, dev, R, K, sigma):
         P(vals), P(comps), None, None, P(total), ctypes.c_float(1.0 / R), i64(0), i64(N), P(wr),
         ctypes.c_size_t(wr_b), st)))
     # what the Python modules pay end to end: count + offsets + ONE host sync (sizes the lists) + compact
-    t_e2e = median_ms(lambda: native.support_compact(p, support_cols=lists), 10, 2)
+    t_e2e = median_ms(lambda: native.support_compact(p, support_cols=lists, support_vals=vlists), 10, 2)
+    t_e2e_chain = median_ms(lambda: native.support_compact(p, support_cols=lists, fused=False), 10, 2)
     listed = float((lists[:, 0] >= -1).float().mean().item())
 
     def entry(ms, nbytes):
@@ -517,8 +537,14 @@ def compaction_bench(native, dev, R, K, sigma):
             "support_count_cols": entry(t_count_l, listed * 4.0 * cap * R + (1 - listed) * 4.0 * K * R + 4.0 * R),
             "support_compact_cols": entry(t_comp_l, listed * (4.0 * cap * R + 64.0 * N) + (1 - listed) * 4.0 * K * R
                                           + 12.0 * N + 8.0 * (R + 1)),
+            "fused_compact_lists": entry(t_fused, listed * (4.0 * cap * R + 64.0 * N) + (1 - listed) * 8.0 * K * R
+                                         + 12.0 * N + 8.0 * (R + 1)),
+            "fused_compact_lists_vals": entry(t_fused_v, listed * 8.0 * cap * R + (1 - listed) * 8.0 * K * R
+                                              + 12.0 * N + 8.0 * (R + 1)),
             "weighted_loss_reduce_fwd": entry(t_red, 8.0 * N),
             "python_support_compact_from_lists_ms": t_e2e,
+            "python_support_compact_from_lists_chain_ms": t_e2e_chain,
+            "sparsemax_fwd_cols_ms": t_fwd_cols, "sparsemax_fwd_lists_ms": t_fwd_lists,
             "note": "frac = bytes the launch has to move / time / 8 TB/s; the list-fed forms read the "
                     "forward's support lists instead of p (64-byte sector per gathered probability)"}
 
@@ -580,6 +606,62 @@ def train_steps_bench(dev, world, rank):
     res["cfg5_bitvae_sparsemap_128bits_b1024_per_gpu"]["grad_allreduce"] = (
         f"1 bucket of {sum(p.numel() for p in m.parameters()) * 4 / 1e6:.1f} MB over {world} rank(s)")
     return res
+
+
+def make_digest(out, a):
+    """A few hundred characters: per sweep entry [rows/s, fwd_frac, bwd_frac, fwd_bwd_frac] (fractions
+    of the 8 TB/s peak on the least bytes the launches have to move), the headline's rate on
+    SURVEY.md's 20 K streaming model, the compaction chain and the solver's convergence."""
+    r3 = lambda v: None if v is None else float(f"{v:.3g}")
+    k = out["kernels"]
+    d = {"sweep_frac": {f"K{a.K}" if a.sigma == 1.0 else f"K{a.K}_s{a.sigma}":
+                        [r3(a.rows / ((k["sparsemax_fwd"]["ms"] + k["sparsemax_bwd"]["ms"]) * 1e-3)),
+                         r3(k["sparsemax_fwd"]["frac"]), r3(k["sparsemax_bwd"]["frac"]), r3(out["fwd_bwd_frac"])]},
+         "rate_on_20K_model_GBps": r3(20.0 * a.K * a.rows / ((k["sparsemax_fwd"]["ms"] + k["sparsemax_bwd"]["ms"]) * 1e-3) / 1e9),
+         "rate_on_20K_model_note": "may exceed the 8000 GB/s peak: the list backward reads O(support) "
+                                   "bytes instead of the dy and p rows"}
+    for tag, e in out.get("sweep", {}).items():
+        d["sweep_frac"][tag.replace("sigma", "s").replace("adversarial", "adv")] = [
+            r3(e["rows_per_s"]), r3(e["fwd_frac"]), r3(e["bwd_frac"]), r3(e["fwd_bwd_frac"])]
+    if out.get("compaction"):
+        d["compaction_ms"] = {f'K{c["K"]}_s{c["sigma"]}': {kk: r3(c[kk]["ms"]) if isinstance(c[kk], dict) else r3(c[kk])
+                                                          for kk in c if kk.startswith("support_") or kk.startswith("fused") or kk.startswith("python_")
+                              or kk.startswith("sparsemax_fwd_")}
+                              for c in out["compaction"]}
+    sm = out.get("sparsemap") or []
+    if sm:
+        d["sparsemap_converged_frac_min"] = r3(min(e["converged_frac"] for e in sm))
+        d["sparsemap_converged_frac_min_bernoulli"] = r3(min([e["converged_frac"] for e in sm if e["budget"] == 0] or [None]))
+        d["sparsemap_max_marginal_err_all"] = r3(max(e["max_marginal_err_all"] for e in sm))
+        d["sparsemap_max_marginal_err_converged"] = r3(max(e["max_marginal_err_converged"] or 0.0 for e in sm))
+        d["sparsemap_ms"] = {f'{e["B"]}x{e["bits"]}_b{e["budget"]}_s{e["sigma"]:g}': r3(e["fwd_ms"]) for e in sm}
+    sq = out.get("sparsemap_sequence") or []
+    if sq:
+        d["sequence_converged_frac"] = {f'{e["B"]}x{e["positions"]}': r3(e["converged_frac"]) for e in sq}
+    ts = out.get("train_steps") or {}
+    if ts:
+        d["train_step_ms"] = {kk: r3(v["ms_per_step"]) for kk, v in ts.items()}
+    return d
+
+
+def tail_digest(d):
+    """The digest cut down to what fits the driver's tail of the line: [fwd, bwd, fwd+bwd] fractions
+    per sweep entry, list-fed compaction end to end, solver convergence, cfg5 step."""
+    t = {"frac_fwd_bwd_both": {k: v[1:] for k, v in d["sweep_frac"].items()},
+         "rate_on_20K_model_GBps": d["rate_on_20K_model_GBps"]}
+    if "compaction_ms" in d:
+        t["compact_from_lists_ms_kernel_e2e"] = {k: [v.get("fused_compact_lists_vals"), v.get("python_support_compact_from_lists_ms")]
+                                                 for k, v in d["compaction_ms"].items()}
+    for k in ("sparsemap_converged_frac_min", "sparsemap_converged_frac_min_bernoulli",
+              "sparsemap_max_marginal_err_all", "sparsemap_max_marginal_err_converged", "sequence_converged_frac"):
+        if k in d:
+            t[k.replace("sparsemap_", "sm_")] = d[k]
+    if "sparsemap_ms" in d:
+        t["sm_ms"] = {k: v for k, v in d["sparsemap_ms"].items() if k.endswith("_s1") and "x128" in k}
+    if "train_step_ms" in d:
+        t["step_ms"] = {k.split("_")[0] + ("_compact" if "compact" in k else ""): v for k, v in d["train_step_ms"].items()
+                        if "init_support" not in k and "dense_logits" not in k and "hoisted" not in k and "topk" not in k}
+    return t
 
 
 def main():
@@ -778,6 +860,12 @@ def main():
         out["sparsemap_cpu_baseline"] = sparsemap_cpu_baseline(8192, 128, 0, 1.0)   # ~5 s on one core
         out["sparsemap_cpu_baseline_all_cores"] = sparsemap_cpu_baseline_all_cores(32768, 128, 0, 1.0)
     if rank == 0:
+        # The driver's record keeps `config`, `roofline`, `cpu_baseline` whole and otherwise only the
+        # last ~2000 characters of this line: the compact digest of the sweep / compaction / solver
+        # blocks goes into `roofline` AND to the very end of the line.
+        digest = make_digest(out, a)
+        out["roofline"]["digest"] = digest
+        out["digest_tail"] = tail_digest(digest)   # last key of the line, < 1500 characters
         print(json.dumps(out))
     if _dist_on():
         import torch.distributed as dist

@@ -81,6 +81,17 @@ int smlvm_sparsemax_bwd_cols(const float* dy, const int32_t* support_cols, int32
                              const uint32_t* support_mask, const float* p,
                              const int32_t* supp_size, float* dx, int64_t R, int32_t K,
                              void* stream);
+/* smlvm_sparsemax_fwd_cols that also leaves the VALUES of the listed non-zeros:
+ *   support_vals [R, cap] fp32, slot for slot with support_cols (slots without a column are not
+ *   written); the same bits as p at those columns.  With them smlvm_support_compact_fused gathers
+ *   nothing from p: this is the sparsemax epilogue that feeds the compaction of
+ *   lvmhelpers/structmarg.py:113-126 / the support-only mode of marg.py:86-105.
+ * K <= 4096 and cap <= 64 (the one-wave-per-row kernels; SMLVM_ERR_UNSUPPORTED beyond);
+ * support_vals == NULL: exactly smlvm_sparsemax_fwd_cols. */
+int smlvm_sparsemax_fwd_lists(const float* x, float* p, int32_t* supp_size, int32_t* nnz, float* tau,
+                              float* entropy, int32_t* support_cols, float* support_vals,
+                              int32_t cap, uint32_t* support_mask, int64_t R, int32_t K,
+                              void* stream);
 
 /* Shannon entropy with exact zeros, lvmhelpers/marg.py:6-28 (also structmarg.py:9-20):
  * ent[r] = -sum_{p>0} pc*log(pc), pc = clamp(p, eps, 1-eps), eps = FLT_EPSILON. */
@@ -135,12 +146,36 @@ int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_offsets, int6
  * a list are counted / compacted from its <= cap entries (sorted by column on the fly, so the
  * output order is unchanged) and only gather their probabilities; rows marked -2 are scanned.
  * This is the "fused into the sparsemax epilogue" form of the reference's boolean-mask compaction
- * (lvmhelpers/structmarg.py:113-126): 12 N + 4 cap R bytes instead of 4 K R + 12 N. */
+ * (lvmhelpers/structmarg.py:113-126): 12 N + 4 cap R bytes instead of 4 K R + 12 N.
+ * These two take cap <= 64 (SMLVM_ERR_INVALID beyond): the 128-slot lists that
+ * smlvm_sparsemax_fwd_cols can write for K > 4096 feed the backward only -- count / compact such
+ * rows from p (support_cols = NULL). */
 int smlvm_support_count_cols(const float* p, const int32_t* support_cols, int32_t cap, int32_t* nnz,
                              int64_t R, int32_t K, void* stream);
 int smlvm_support_compact_cols(const float* p, const int32_t* support_cols, int32_t cap,
                                const int64_t* row_offsets, int32_t* rows, int32_t* cols, float* vals,
                                int64_t R, int32_t K, void* stream);
+/* Count + offsets + compaction in ONE launch (round 3): the boolean-mask compaction of
+ * lvmhelpers/structmarg.py:113-126 (and marg.py:86-87's live-column test) as a single pass over the
+ * forward's lists.  Same row_offsets / rows / cols / vals as the three calls above, bit for bit.
+ *   support_cols [R, cap] nullable (cap in {16, 32, 64}, 16-byte aligned): rows with a list are
+ *       taken from it, rows marked -2 / -3 and all rows when it is NULL are scanned from p;
+ *   support_vals [R, cap] nullable (smlvm_sparsemax_fwd_lists): values of the listed entries; NULL:
+ *       they are gathered from p;
+ *   row_offsets [R+1] int64: always complete, row_offsets[R] = N;
+ *   rows / cols / vals (each nullable): capacity n_cap entries each -- entries at positions >=
+ *       n_cap are dropped, so a caller that does not know N sizes them by an upper bound (R * cap
+ *       when every row has a list) or calls again with n_cap = N and the offsets it now has;
+ *   workspace: smlvm_support_compact_fused_workspace_bytes(R) bytes, 8-byte aligned, cleared by the
+ *       call itself; afterwards word 2 (uint64) holds N and word 1 is non-zero if a tile gave up
+ *       waiting for the tiles before it (bounded wait; every result of that launch is void then).
+ * Tiles of 512 rows exchange their totals through the workspace (decoupled look-back): no second
+ * pass over the lists, no host round trip between counting and compacting. */
+size_t smlvm_support_compact_fused_workspace_bytes(int64_t R);
+int smlvm_support_compact_fused(const float* p, const int32_t* support_cols, const float* support_vals,
+                                int32_t cap, int64_t* row_offsets, int32_t* rows, int32_t* cols,
+                                float* vals, int64_t n_cap, int64_t R, int32_t K, void* workspace,
+                                size_t workspace_bytes, void* stream);
 size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N);
 int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps, const int64_t* row_offsets,
                                    float* row_out, float* total, float inv_b, int64_t R, int64_t N,

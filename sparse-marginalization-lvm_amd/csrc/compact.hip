@@ -10,6 +10,10 @@
 
 #include <mutex>
 
+#ifndef SMLVM_FUSED_WAVES
+#define SMLVM_FUSED_WAVES 8
+#endif
+
 namespace smlvm {
 
 constexpr int kScanItemsPerBlock = 2048;  // 256 threads x 8 items
@@ -438,6 +442,321 @@ __global__ __launch_bounds__(256) void support_compact_lists_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------- fused single pass
+// smlvm_support_compact_fused: count + exclusive scan + compaction in ONE launch (round 3; the
+// chain count -> three scan launches -> compact read the lists twice and cost five launches).
+// A workgroup of 8 waves takes a tile of 512 consecutive rows: phase A counts every row (from its support
+// list, or by scanning p for rows without one), the counts are scanned in the block, the
+// tile's total is published and the exclusive prefix of the tiles before it comes from a decoupled
+// look-back over their status words (one 64-bit word per tile: 2 flag bits + 62 value bits, so a
+// word is consistent by itself and relaxed device-scope atomics suffice); phase B writes the row
+// offsets and the compacted entries.  Tiles are handed out by a ticket counter, so every tile a
+// look-back waits for has already started and publishes its total without waiting for anyone.
+// The wait is bounded all the same (kLookbackSpins polls, then the tile gives up, raises the
+// error word of the workspace and every later result of the launch is void): no wave can spin
+// forever.  With the forward's value lists (smlvm_sparsemax_fwd_lists) nothing is gathered from p.
+constexpr int kFusedWaves = SMLVM_FUSED_WAVES;            // waves per workgroup = 64-row slices per tile
+constexpr int kFusedTileRows = 64 * kFusedWaves;
+constexpr unsigned long long kTileAggregate = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1ull;
+constexpr int kLookbackSpins = 1 << 22;
+
+// workspace: [0] ticket counter, [1] error word, [2] N (copy of row_offsets[R]), [3] reserved,
+// [4 ...] one status word per tile; all zero before the launch (the entry point clears it)
+struct FusedWs { unsigned long long* w; };
+
+__device__ __forceinline__ void compact_step4_lim(float4 v, int f, int64_t row, int64_t& out, int64_t lim,
+                                                  int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                                  float* __restrict__ vals)
+{
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    unsigned long long m[4];
+    int pre = 0, total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m[c] = __ballot(e[c] > 0.0f);
+        pre += lanes_below(m[c]);
+        total += __popcll(m[c]);
+    }
+    if (total == 0) return;
+    int64_t pos = out + pre;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (e[c] > 0.0f) {
+            if (pos < lim) {
+                if (rows) rows[pos] = (int32_t)row;
+                if (cols) cols[pos] = f * 4 + c;
+                if (vals) vals[pos] = e[c];
+            }
+            ++pos;
+        }
+    }
+    out += total;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void compact_row_scan_lim(const float* __restrict__ pr, int K, int lane,
+                                                     int64_t row, int64_t out, int64_t lim,
+                                                     int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+                                                     float* __restrict__ vals)
+{
+    if constexpr (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pr);
+        const int K4 = K >> 2;
+        for (int f0 = 0; f0 < K4; f0 += 64) {
+            const int f = f0 + lane;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < K4) v = p4[f];
+            compact_step4_lim(v, f, row, out, lim, rows, cols, vals);
+        }
+    } else {
+        for (int j0 = 0; j0 < K; j0 += 64) {
+            const int j = j0 + lane;
+            const float v = j < K ? pr[j] : 0.0f;
+            const unsigned long long m = __ballot(v > 0.0f);
+            if (m == 0ull) continue;
+            if (v > 0.0f) {
+                const int64_t pos = out + lanes_below(m);
+                if (pos < lim) {
+                    if (rows) rows[pos] = (int32_t)row;
+                    if (cols) cols[pos] = j;
+                    if (vals) vals[pos] = v;
+                }
+            }
+            out += __popcll(m);
+        }
+    }
+}
+
+// G lanes per row (cap = 4 G), S = G steps of 64 / G rows per wave: 64 rows per wave, 64 x
+// kFusedWaves per tile.
+// lists == nullptr: every row is scanned (G only fixes the shape of the loop then).
+// exclusive scan of one value per thread over a workgroup of NW waves (NW <= 16)
+template <int NW>
+__device__ __forceinline__ long long block_exclusive_scan_nw(long long v, long long* lds, long long& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        long long s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+template <int G, bool VEC>
+__global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel(
+    const float* __restrict__ p, const int32_t* __restrict__ lists, const float* __restrict__ vlists,
+    int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows, int32_t* __restrict__ cols,
+    float* __restrict__ vals, int64_t n_cap, int64_t R, int K, unsigned long long* __restrict__ ws)
+{
+    constexpr int RW = 64 / G, S = G, CAP = 4 * G;
+    __shared__ int cnt[kFusedTileRows];
+    __shared__ long long offs[kFusedTileRows];
+    __shared__ long long scan_lds[kFusedWaves];
+    __shared__ long long tile_info[2];      // [0] ticket, [1] exclusive prefix of the tile
+    __shared__ int parked[kFusedWaves][64 * 4];
+    // a step's entries are staged here in output order and leave as dense, coalesced stores (each
+    // lane storing its own few entries cost 12 sparse store instructions per step: the launch was
+    // bound by their issue, not by bytes)
+    __shared__ int stage_c[kFusedWaves][64 * 4];
+    __shared__ float stage_v[kFusedWaves][64 * 4];
+    __shared__ unsigned char stage_g[kFusedWaves][64 * 4];
+    const int lane = threadIdx.x & 63, gl = lane % G, grp = lane / G, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        tile_info[0] = (long long)__hip_atomic_fetch_add(&ws[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int64_t tile = tile_info[0];
+    const int64_t ntiles = (R + kFusedTileRows - 1) / kFusedTileRows;
+    if (tile >= ntiles) return;             // (never: the grid has exactly ntiles blocks)
+    const int64_t row_base = tile * kFusedTileRows + wave * 64;
+
+    // ---- phase A: counts
+    int4 q[S];
+    unsigned long long unl_steps[S];       // per step: ballot of (gl == 0 && the row has no list)
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int64_t row = row_base + s * RW + grp;
+        q[s] = make_int4(-1, -1, -1, -1);
+        if (lists) { if (row < R) q[s] = reinterpret_cast<const int4*>(lists + row * CAP)[gl]; }
+        else q[s].x = -2;
+        const int first = __shfl(q[s].x, grp * G);
+        const bool unlisted = first < -1;
+        const int n = lanes_sum<G>((q[s].x >= 0) + (q[s].y >= 0) + (q[s].z >= 0) + (q[s].w >= 0));
+        unl_steps[s] = __ballot(unlisted && gl == 0 && row < R);
+        if (gl == 0) cnt[wave * 64 + s * RW + grp] = (row < R && !unlisted) ? n : 0;
+        if (unlisted) q[s] = make_int4(-1, -1, -1, -1);
+    }
+    // without value lists the listed entries' probabilities are gathered from p now, while the
+    // counts are scanned and the look-back waits (K = 256: 0.191 -> 0.167 ms; fetching the value
+    // lists this early instead of in phase B was measured too: 0.125 -> 0.135 ms, not kept)
+    float4 pv[S];
+    if (vals && !vlists) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int64_t row = row_base + s * RW + grp;
+            pv[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q[s].x >= 0) {
+                const float* pr = p + row * K;
+                pv[s].x = pr[q[s].x];
+                if (q[s].y >= 0) pv[s].y = pr[q[s].y];
+                if (q[s].z >= 0) pv[s].z = pr[q[s].z];
+                if (q[s].w >= 0) pv[s].w = pr[q[s].w];
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
+            const int g = __builtin_ctzll(todo) / G;
+            const int64_t r = row_base + s * RW + g;
+            const int c = count_row_scan<VEC>(p + r * K, K, lane);
+            if (lane == 0) cnt[wave * 64 + s * RW + g] = c;
+        }
+    }
+    __syncthreads();
+    long long total;
+    const long long mine = cnt[threadIdx.x];
+    const long long ex = block_exclusive_scan_nw<kFusedWaves>(mine, scan_lds, total);
+
+    // ---- the tile's exclusive prefix: decoupled look-back (wave 0)
+    if (wave == 0) {
+        unsigned long long* status = ws + 4;
+        if (lane == 0)
+            __hip_atomic_store(&status[tile], (tile == 0 ? kTilePrefix : kTileAggregate) | (unsigned long long)total,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long excl = 0;
+        if (tile > 0) {
+            int64_t look = tile - 1;
+            int spins = 0;
+            for (;;) {
+                const int64_t idx = look - lane;
+                unsigned long long w = kTilePrefix;   // before tile 0: an inclusive prefix of zero
+                if (idx >= 0) w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned flag = (unsigned)(w >> 62);
+                const unsigned long long m_inv = __ballot(flag == 0u), m_pre = __ballot(flag == 2u);
+                const int first_p = m_pre ? __builtin_ctzll(m_pre) : 64;
+                const unsigned long long need = first_p >= 63 ? ~0ull : ((2ull << first_p) - 1ull);
+                if ((m_inv & need) != 0ull) {         // a tile in the window has not published yet
+                    if (++spins > kLookbackSpins) {
+                        if (lane == 0) __hip_atomic_store(&ws[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                long long v = (lane <= first_p) ? (long long)(w & kTileValue) : 0ll;
+                v = (long long)group_reduce<64>((double)v, OpSum{});   // exact: < 2^53
+                excl += v;
+                if (first_p < 64) break;
+                look -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&status[tile], kTilePrefix | (unsigned long long)(excl + total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) tile_info[1] = excl;
+    }
+    __syncthreads();
+    const long long prefix = tile_info[1];
+
+    // ---- phase B: offsets, then the entries
+    {
+        const int64_t row = tile * kFusedTileRows + threadIdx.x;
+        const long long o = prefix + ex;
+        offs[threadIdx.x] = o;
+        if (row < R) row_offsets[row] = o;
+        if (row == R - 1) {
+            row_offsets[R] = o + mine;
+            __hip_atomic_store(&ws[2], (unsigned long long)(o + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!rows && !cols && !vals) return;
+    int* my_park = parked[wave] + grp * CAP;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int64_t row = row_base + s * RW + grp;
+        const int c[4] = {q[s].x, q[s].y, q[s].z, q[s].w};
+        const bool any = c[0] >= 0;            // entries are packed at the front of a list
+        if (__ballot(any) != 0ull) {
+            int n = (c[0] >= 0) + (c[1] >= 0) + (c[2] >= 0) + (c[3] >= 0);
+            n = lanes_sum<G>(n);
+            const int n_max = group_reduce<64>(n, OpMaxI{});
+            wave_lds_sync();
+            reinterpret_cast<int4*>(my_park)[gl] = q[s];
+            wave_lds_sync();
+            float4 pvl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vals && vlists && any) pvl = reinterpret_cast<const float4*>(vlists + row * CAP)[gl];
+            int rank[4] = {0, 0, 0, 0};
+            for (int k = 0; k < n_max; k += 4) {   // wave-uniform trip count; four entries per LDS read
+                const int4 o4 = reinterpret_cast<const int4*>(my_park)[k >> 2];
+                const unsigned other[4] = {(unsigned)o4.x, (unsigned)o4.y, (unsigned)o4.z, (unsigned)o4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)      // -1 padding: larger than every column
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) rank[i] += other[u] < (unsigned)c[i] ? 1 : 0;
+            }
+            const long long out = offs[wave * 64 + s * RW + grp];
+            const float4 pvs = vlists ? pvl : pv[s];
+            const float pvv[4] = {pvs.x, pvs.y, pvs.z, pvs.w};
+            if (unl_steps[s] == 0ull) {
+                // every row of the step has its list: the step's entries are one contiguous run of
+                // the output, from the first row's offset to the next step's
+                const long long base = offs[wave * 64 + s * RW];
+                const int first_next = wave * 64 + (s + 1) * RW;
+                // (the last step of the tile ends at prefix + total)
+                const long long end = first_next < kFusedTileRows ? offs[first_next] : prefix + total;
+                const int run = (int)(end - base);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c[i] >= 0) {
+                        const int slot = (int)(out - base) + rank[i];
+                        stage_c[wave][slot] = c[i];
+                        stage_g[wave][slot] = (unsigned char)grp;
+                        if (vals) stage_v[wave][slot] = pvv[i];
+                    }
+                }
+                wave_lds_sync();
+                for (int e = lane; e < run; e += 64) {
+                    const int64_t pos = base + e;
+                    if (pos < n_cap) {
+                        if (rows) rows[pos] = (int32_t)(row_base + s * RW + stage_g[wave][e]);
+                        if (cols) cols[pos] = stage_c[wave][e];
+                        if (vals) vals[pos] = stage_v[wave][e];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t pos = out + rank[i];
+                    if (c[i] >= 0 && pos < n_cap) {
+                        if (rows) rows[pos] = (int32_t)row;
+                        if (cols) cols[pos] = c[i];
+                        if (vals) vals[pos] = pvv[i];
+                    }
+                }
+            }
+        }
+        for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
+            const int g = __builtin_ctzll(todo) / G;
+            const int64_t r = row_base + s * RW + g;
+            compact_row_scan_lim<VEC>(p + r * K, K, lane, r, offs[wave * 64 + s * RW + g], n_cap, rows, cols, vals);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- weighted reduce
 // Fixed-shape, order-deterministic two-stage sum: stage 1 gives each of up to kRedBlocks blocks a
 // contiguous slice of the N products (fp64), stage 2 folds the partials in index order.
@@ -673,6 +992,44 @@ extern "C" int smlvm_support_compact_cols(const float* p, const int32_t* support
                                           float* vals, int64_t R, int32_t K, void* stream)
 {
     return support_compact_go(p, support_cols, cap, row_offsets, rows, cols, vals, R, K, stream);
+}
+
+extern "C" size_t smlvm_support_compact_fused_workspace_bytes(int64_t R)
+{
+    const int64_t ntiles = R <= 0 ? 0 : (R + kFusedTileRows - 1) / kFusedTileRows;
+    return (size_t)(4 + ntiles) * sizeof(unsigned long long);
+}
+
+extern "C" int smlvm_support_compact_fused(const float* p, const int32_t* support_cols,
+                                           const float* support_vals, int32_t cap,
+                                           int64_t* row_offsets, int32_t* rows, int32_t* cols,
+                                           float* vals, int64_t n_cap, int64_t R, int32_t K,
+                                           void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (R < 0 || K < 1 || n_cap < 0 || !row_offsets) return SMLVM_ERR_INVALID;
+    if (support_cols && !(cap == 16 || cap == 32 || cap == 64)) return SMLVM_ERR_INVALID;
+    if (support_cols && !aligned16(support_cols)) return SMLVM_ERR_INVALID;
+    if (support_vals && (!support_cols || !aligned16(support_vals))) return SMLVM_ERR_INVALID;
+    const size_t need = smlvm_support_compact_fused_workspace_bytes(R);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return SMLVM_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return SMLVM_ERR_HIP;
+    if (R == 0) {
+        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        return SMLVM_OK;
+    }
+    if (!p) return SMLVM_ERR_INVALID;
+    const bool vec = K % 4 == 0 && aligned16(p);
+    const unsigned grid = (unsigned)((R + kFusedTileRows - 1) / kFusedTileRows);
+    unsigned long long* ws = static_cast<unsigned long long*>(workspace);
+#define SMLVM_FUSED(G)                                                                                      \
+    if (vec) hipLaunchKernelGGL((support_compact_fused_kernel<G, true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws); \
+    else hipLaunchKernelGGL((support_compact_fused_kernel<G, false>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws)
+    if (support_cols && cap == 16) { SMLVM_FUSED(4); }
+    else if (support_cols && cap == 64) { SMLVM_FUSED(16); }
+    else { SMLVM_FUSED(8); }
+#undef SMLVM_FUSED
+    return check_launch();
 }
 
 extern "C" size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N)

@@ -615,19 +615,26 @@ template <int Q, int G>
 __device__ __forceinline__ int emit_cols_from_candidates(const float (&c)[Q], const int (&cc)[Q],
                                                           float tau, int gl, int grp,
                                                           int32_t* __restrict__ list, int cap, bool live,
-                                                          int mark = kColsOverflow)
+                                                          int mark = kColsOverflow, long long vdelta = 0)
 {
+    // vdelta != 0: the row's probabilities go to the value list at byte distance vdelta from the
+    // column list, slot for slot (smlvm_sparsemax_fwd_lists: the compaction then needs no gather)
     int base = 0;
     bool wrote0 = false;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const bool nz = (c[q] - tau) > 0.0f;
+        const float pv = c[q] - tau;
+        const bool nz = pv > 0.0f;
         const unsigned long long m = __ballot(nz);
         if (m != 0ull) {
             int cnt, below;
             group_count<G>(m, gl, grp, cnt, below);
             const int off = base + below;
-            if (nz && live && off < cap) { list[off] = cc[q]; wrote0 = wrote0 || off == 0; }
+            if (nz && live && off < cap) {
+                list[off] = cc[q];
+                wrote0 = wrote0 || off == 0;
+                if (vdelta) *reinterpret_cast<float*>(reinterpret_cast<char*>(list + off) + vdelta) = pv;
+            }
             base += cnt;
         }
     }
@@ -650,7 +657,8 @@ template <int E, int NW, bool CAND, bool VEC, class Red>
 __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* cand, int K, int& supp,
                                               float& tau_out, int& n_listed,
                                               int32_t* list = nullptr, int cap = 0,
-                                              bool live = true, int mark = kColsOverflow)
+                                              bool live = true, int mark = kColsOverflow,
+                                              long long vdelta = 0)
 {
     const float floor_k = cand_floor(K);
     const float margin = kLazyMargin;
@@ -842,7 +850,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
                 const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
                 n_listed = emit_cols_from_candidates<kCandPerLane, 64>(
-                    c, cc, tau_c, lane, 0, list, cap, live && (NW == 1 || threadIdx.x < 64), mark);
+                    c, cc, tau_c, lane, 0, list, cap, live && (NW == 1 || threadIdx.x < 64), mark, vdelta);
             }
         }
     }
@@ -866,7 +874,8 @@ template <int E, int G, bool VEC>
 __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& red, float* cand, int K,
                                                     int& supp, float& tau_out, int& n_listed,
                                                     int32_t* list = nullptr, int cap = 0,
-                                                    bool live = true, int mark = kColsOverflow)
+                                                    bool live = true, int mark = kColsOverflow,
+                                                    long long vdelta = 0)
 {
     const float floor_k = cand_floor(K);
     static_assert(G < 64, "lane groups inside one wave");
@@ -973,7 +982,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     if (fast) {
         if (list) {
             const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-            n_listed = emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live, mark);
+            n_listed = emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live, mark, vdelta);
             listed = true;
         }
     } else {
@@ -1174,7 +1183,7 @@ __device__ __forceinline__ void bwd_row_gather_bits(const float* __restrict__ dy
 template <int E, int G, bool VEC>
 __device__ __forceinline__ int emit_support_cols(const float (&p)[E], int gl, int grp,
                                                   int32_t* __restrict__ list, int cap, bool live,
-                                                  int mark = kColsOverflow)
+                                                  int mark = kColsOverflow, long long vdelta = 0)
 {
     if constexpr (G < 64) {
         // several rows per wave: count per lane, scan over the group's lanes, and only rows whose
@@ -1191,7 +1200,10 @@ __device__ __forceinline__ int emit_support_cols(const float (&p)[E], int gl, in
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const bool nz = p[e] > 0.0f;
-                if (nz && fits && live) list[off] = col_of<E, VEC>(e, gl, G);
+                if (nz && fits && live) {
+                    list[off] = col_of<E, VEC>(e, gl, G);
+                    if (vdelta) *reinterpret_cast<float*>(reinterpret_cast<char*>(list + off) + vdelta) = p[e];
+                }
                 off += nz ? 1 : 0;
             }
         }
@@ -1211,7 +1223,11 @@ __device__ __forceinline__ int emit_support_cols(const float (&p)[E], int gl, in
                 int cnt, below;
                 group_count<G>(m, gl, grp, cnt, below);
                 const int off = base + below;
-                if (nz && live && off < cap) { list[off] = col_of<E, VEC>(e, gl, G); wrote0 = wrote0 || off == 0; }
+                if (nz && live && off < cap) {
+                    list[off] = col_of<E, VEC>(e, gl, G);
+                    wrote0 = wrote0 || off == 0;
+                    if (vdelta) *reinterpret_cast<float*>(reinterpret_cast<char*>(list + off) + vdelta) = p[e];
+                }
                 base += cnt;
             }
         }
@@ -1456,7 +1472,8 @@ template <int G, int E, bool VEC, bool FULL, bool EXTRA>
 __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) void sparsemax_fwd_wave_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ supp,
     int32_t* __restrict__ nnz, float* __restrict__ tau, float* __restrict__ ent,
-    int32_t* __restrict__ cols, int cap, uint32_t* __restrict__ mask, int64_t R, int K)
+    int32_t* __restrict__ cols, int cap, uint32_t* __restrict__ mask, int64_t R, int K,
+    long long vdelta)
 {
     const int lane = threadIdx.x & 63;
     const int gl = lane % G;
@@ -1480,12 +1497,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
     int n_listed = 0;   // #{p > 0} as counted by whoever wrote (or gave up on) the row's list
     if constexpr (GCAND)
         listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, K, s, t,
-                                                n_listed, list, cap, live, mark);
+                                                n_listed, list, cap, live, mark, vdelta);
     else
         listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
-                                                K, s, t, n_listed, list, cap, live, mark);
+                                                K, s, t, n_listed, list, cap, live, mark, vdelta);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
-    if (cols && !listed) n_listed = emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark);
+    if (cols && !listed) n_listed = emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark, vdelta);
     if constexpr (MASKS) {
         // The row was marked kColsMask exactly when that count exceeded cap (wave-uniform here; NOT
         // supp_size, which counts passing ranks and can differ from #{p > 0} with ties at the
@@ -2148,6 +2165,7 @@ struct FwdArgs {
     bool vec, extra;
     int32_t* cols; int cap;
     uint32_t* mask;
+    float* vals = nullptr;   // value lists (K <= 4096 only), slot for slot with cols
 };
 struct BwdArgs {
     const float* dy; const float* p; const int32_t* supp; float* dx;
@@ -2170,7 +2188,9 @@ static void fwd_wave_go(const FwdArgs& a)
 {
     hipLaunchKernelGGL((sparsemax_fwd_wave_kernel<G, E, VEC, FULL, EXTRA>), dim3(wave_grid(a.R, G)),
                        dim3(64 * kWavesPerBlock), 0, a.st, a.x, a.p, a.supp, a.nnz, a.tau, a.ent,
-                       a.cols, a.cap, a.mask, a.R, a.K);
+                       a.cols, a.cap, a.mask, a.R, a.K,
+                       (long long)((a.cols && a.vals) ? reinterpret_cast<const char*>(a.vals) -
+                                                            reinterpret_cast<const char*>(a.cols) : 0));
 }
 template <int NW, int E, bool VEC, bool FULL, bool EXTRA>
 static void fwd_block_go(const FwdArgs& a)
@@ -2544,6 +2564,25 @@ extern "C" int smlvm_sparsemax_fwd_cols(const float* x, float* p, int32_t* supp_
               (support_cols && K > 32 && K <= 4096) ? support_mask : nullptr};
     if (K > 65536) launch_fwd_stream(a);
     else SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_sparsemax_fwd_lists(const float* x, float* p, int32_t* supp_size, int32_t* nnz,
+                                         float* tau, float* entropy, int32_t* support_cols,
+                                         float* support_vals, int32_t cap, uint32_t* support_mask,
+                                         int64_t R, int32_t K, void* stream)
+{
+    if (!support_vals)
+        return smlvm_sparsemax_fwd_cols(x, p, supp_size, nnz, tau, entropy, support_cols, cap, support_mask, R, K, stream);
+    if (R < 0 || K < 1 || !support_cols) return SMLVM_ERR_INVALID;
+    if (K > 4096) return SMLVM_ERR_UNSUPPORTED;   // value lists: the one-wave-per-row kernels only
+    if (cap < 1 || cap > kColsMaxCap) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!x || !p || !supp_size) return SMLVM_ERR_INVALID;
+    FwdArgs a{x, p, supp_size, nnz, tau, entropy, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(x) && aligned16(p), nnz || tau || entropy, support_cols, cap,
+              K > 32 ? support_mask : nullptr, support_vals};
+    SMLVM_DISPATCH(launch_fwd_wave, launch_fwd_block, a);
     return check_launch();
 }
 

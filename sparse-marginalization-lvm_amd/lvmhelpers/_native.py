@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
     "smlvm_support_offsets_noalloc",
     "smlvm_sparsemax_support_mask_bytes", "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
+    "smlvm_sparsemax_fwd_lists", "smlvm_support_compact_fused_workspace_bytes", "smlvm_support_compact_fused",
     "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
@@ -50,6 +51,8 @@ def lib():
         L.smlvm_sparsemax_support_mask_bytes.restype = ctypes.c_size_t
         L.smlvm_sparsemax_support_mask_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.smlvm_support_offsets_workspace_bytes.argtypes = [ctypes.c_int64]
+        L.smlvm_support_compact_fused_workspace_bytes.restype = ctypes.c_size_t
+        L.smlvm_support_compact_fused_workspace_bytes.argtypes = [ctypes.c_int64]
         L.smlvm_weighted_loss_reduce_workspace_bytes.restype = ctypes.c_size_t
         L.smlvm_weighted_loss_reduce_workspace_bytes.argtypes = [ctypes.c_int64]
         L.smlvm_sparsemap_fwd_workspace_bytes.restype = ctypes.c_size_t
@@ -105,12 +108,14 @@ def support_cols_cap(K):
 
 
 def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False,
-                  want_mask=False):
+                  want_mask=False, want_vals=False):
     """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None).
     want_cols=True appends the support lists [R, support_cols_cap(K)] i32 for sparsemax_bwd_cols;
     want_mask=True (with want_cols) appends the support-mask buffer as well (None when the shape
     has none: only 1024 < K <= 4096), which lets the backward skip p for rows with more non-zeros
-    than a list holds."""
+    than a list holds.  want_vals=True (with want_cols, K <= 4096) appends the value lists
+    [R, cap] f32 (the probabilities of the listed columns, slot for slot; None for wider rows) that
+    let `support_compact` run without gathering from p."""
     x = _need_gpu(x, torch.float32, "x")
     R, K = x.shape
     p = torch.empty_like(x)
@@ -131,13 +136,18 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
         if nbytes:
             # zeroed: a row is only ever marked -3 after its bits were written, this is defence
             mask = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
+    vals = torch.empty((R, cap), dtype=torch.float32, device=x.device) if (want_vals and K <= 4096) else None
     with torch.cuda.device(x.device):
-        _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
-                                              _p(cols), _i32(cap), _p(mask), _i64(R),
-                                              _i32(K), _stream()), "smlvm_sparsemax_fwd_cols")
-    if want_mask:
-        return p, supp, nnz, tau, ent, cols, mask
-    return p, supp, nnz, tau, ent, cols
+        if vals is not None:
+            _check(lib().smlvm_sparsemax_fwd_lists(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
+                                                   _p(cols), _p(vals), _i32(cap), _p(mask), _i64(R),
+                                                   _i32(K), _stream()), "smlvm_sparsemax_fwd_lists")
+        else:
+            _check(lib().smlvm_sparsemax_fwd_cols(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
+                                                  _p(cols), _i32(cap), _p(mask), _i64(R),
+                                                  _i32(K), _stream()), "smlvm_sparsemax_fwd_cols")
+    out = (p, supp, nnz, tau, ent, cols) + ((mask,) if want_mask else ()) + ((vals,) if want_vals else ())
+    return out
 
 
 def sparsemax_bwd_cols(dy, cols, p, supp, mask=None):
@@ -247,18 +257,84 @@ def support_row_offsets(p, nnz=None, support_cols=None):
     return support_offsets(nnz)
 
 
+FUSED_MAX_BOUND = 1 << 27   # entries: the largest upper bound the single-pass form allocates for
+FUSED_SMALL = 1 << 22       # R * K up to which the bound is simply R * K
+
+
+def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=True, want_cols=True,
+                          want_vals=True, n_cap=None):
+    """Count + offsets + compaction in ONE launch (smlvm_support_compact_fused) and one host sync
+    (N).  The outputs are sized by an upper bound on N -- R * cap when the rows have lists, R * K
+    for small matrices -- and returned as views of length N; should N exceed the bound (rows
+    without a list in a list-fed call) the entries are redone from the offsets.  Returns
+    (row_offsets, rows, cols, vals) like support_compact, or None when no affordable bound exists."""
+    p = _need_gpu(p, torch.float32, "p")
+    R, K = p.shape
+    dev = p.device
+    cap = 0
+    if support_cols is not None:
+        support_cols = _need_gpu(support_cols, torch.int32, "support_cols")
+        cap = support_cols.shape[1]
+        if support_cols.dim() != 2 or support_cols.shape[0] != R:
+            raise ValueError("support_cols must be [R, cap]")
+        if cap not in (16, 32, 64):
+            support_cols, support_vals, cap = None, None, 0
+    if support_vals is not None:
+        support_vals = _need_gpu(support_vals, torch.float32, "support_vals")
+        if support_cols is None or tuple(support_vals.shape) != tuple(support_cols.shape):
+            raise ValueError("support_vals must match support_cols")
+    if n_cap is None:
+        # small matrices: R * K can never overflow; with lists: twice the list capacity per row
+        # (rows without a list -- more than cap non-zeros -- are paid for by the rows with short
+        # ones; should N still exceed it, the entries are redone below)
+        if R * K <= FUSED_SMALL or support_cols is None:
+            n_cap = R * K
+        else:
+            n_cap = R * min(K, 2 * cap)
+        if n_cap > FUSED_MAX_BOUND:
+            return None
+    off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    rows = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_rows else None
+    cols = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_cols else None
+    vals = torch.empty(n_cap, dtype=torch.float32, device=dev) if want_vals else None
+    nbytes = lib().smlvm_support_compact_fused_workspace_bytes(_i64(R))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
+                                                 _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
+                                                 _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
+                                                 _stream()), "smlvm_support_compact_fused")
+    if R == 0:
+        return off, rows, cols, vals
+    err, N = (int(v) for v in ws[1:3].tolist())          # the one host sync
+    if err:
+        raise NativeError("smlvm_support_compact_fused: a tile gave up waiting for the tiles before it")
+    if N > n_cap:   # rows without a list overflowed the bound: the entries again, from the offsets
+        return support_compact(p, want_rows=want_rows, want_cols=want_cols, want_vals=want_vals,
+                               support_cols=support_cols, row_offsets=off, total=N, fused=False)
+    cut = lambda t: None if t is None else t[:N]
+    return off, cut(rows), cut(cols), cut(vals)
+
+
 def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None,
-                    row_offsets=None, total=None):
+                    row_offsets=None, total=None, support_vals=None, fused=None):
     """Row-major (rows, cols, vals) lists of the positive entries of p [R,K] plus row_offsets.
 
     support_cols: the forward's support lists for this very p (`sparsemax_fwd(..., want_cols=True)`,
     or `functional.support_cols_of(p)`): rows that have a list are counted and compacted from it
-    instead of from their K probabilities; the output is the same.
+    instead of from their K probabilities; the output is the same.  support_vals: the forward's
+    value lists (`want_vals=True`): then nothing is gathered from p either.
+    fused=False forces the separate count / offsets / compact launches.
     One host sync (reading N = row_offsets[R]) to size the outputs -- none when the caller has the
     offsets already (`row_offsets` from support_row_offsets and `total` = N read on its side).
     """
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
+    if row_offsets is None and nnz is None and fused is not False:
+        # the single-pass form (one launch, one host sync) whenever an upper bound on N is affordable
+        out = support_compact_fused(p, support_cols, support_vals, want_rows, want_cols, want_vals)
+        if out is not None:
+            return out
     cap = 0
     if support_cols is not None:
         support_cols = _need_gpu(support_cols, torch.int32, "support_cols")

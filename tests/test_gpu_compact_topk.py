@@ -165,6 +165,106 @@ def test_list_fed_kernels_on_handmade_lists(dev, oracle_mod, R, K, cap):
     assert np.array_equal(vals.cpu().numpy(), vals_ref)
 
 
+@pytest.mark.parametrize("R,K,sigma", [(64, 10, 1.0), (64, 256, 1.0), (300, 1000, 1.0), (64, 4096, 1.0),
+                                       (64, 4096, 0.05), (1000, 256, 0.05), (5000, 256, 1.0), (20, 8192, 1.0),
+                                       (257, 4096, 0.2), (1, 64, 1.0), (255, 128, 1.0), (256, 128, 1.0),
+                                       (70000, 64, 1.0)])
+def test_fused_single_pass_compaction(dev, R, K, sigma):
+    """smlvm_support_compact_fused (count + look-back scan + compaction in one launch) against the
+    separate launches: same offsets / rows / cols / vals bit for bit -- fed with nothing (scan of
+    p), with the forward's column lists (probabilities gathered), with column + value lists (nothing
+    gathered), and with an entry capacity below N (the entries beyond it are dropped, the offsets
+    stay complete).  The value lists hold the bits of p at the listed columns."""
+    from lvmhelpers import _native
+    g = torch.Generator(device=dev).manual_seed(R + K)
+    x = torch.empty(R, K, device=dev).normal_(0.0, sigma, generator=g)
+    if K <= 4096:
+        p, _, nnz, _, _, lists, vlists = _native.sparsemax_fwd(x, want_nnz=True, want_cols=True, want_vals=True)
+        p2, _, _, _, _, lists2 = _native.sparsemax_fwd(x, want_cols=True)
+        assert torch.equal(p, p2) and torch.equal(lists, lists2)      # the value lists change nothing else
+        listed = lists[:, 0] >= -1
+        ok = lists >= 0
+        got = vlists[ok & listed[:, None]]
+        want = p.gather(1, lists.clamp(min=0).long())[ok & listed[:, None]]
+        assert torch.equal(got, want)
+    else:
+        p, _, nnz, _, _, lists = _native.sparsemax_fwd(x, want_nnz=True, want_cols=True)
+        lists, vlists = None, None    # 128-slot lists: the backward's only
+    off0, rows0, cols0, vals0 = _native.support_compact(p, fused=False)
+    N = int(off0[R])
+    variants = [(None, None)]
+    if lists is not None:
+        variants += [(lists, None), (lists, vlists)]
+    for sc, sv in variants:
+        out = _native.support_compact_fused(p, sc, sv)
+        assert out is not None
+        off1, rows1, cols1, vals1 = out
+        assert torch.equal(off0, off1) and torch.equal(rows0, rows1)
+        assert torch.equal(cols0, cols1) and torch.equal(vals0, vals1)
+        # capacity below N: a prefix of the entries, complete offsets
+        half = N // 2
+        off2, rows2, cols2, vals2 = _native.support_compact_fused(p, sc, sv, n_cap=half)
+        assert torch.equal(off2, off0)   # (the wrapper redid the entries from the offsets: N > n_cap)
+        assert torch.equal(rows2, rows0) and torch.equal(cols2, cols0) and torch.equal(vals2, vals0)
+    assert torch.equal((off0[1:] - off0[:-1]).to(torch.int32), nnz)
+
+
+@pytest.mark.parametrize("R,K,cap", [(1, 8, 16), (7, 12, 16), (33, 256, 32), (1000, 256, 32), (65, 1000, 64),
+                                     (129, 250, 32), (50, 4096, 64), (257, 37, 32), (3000, 300, 16)])
+def test_fused_compaction_on_handmade_lists(dev, oracle_mod, R, K, cap):
+    """The single-pass compaction on hand-made lists (random order, -1 padding, every third row
+    unlisted with garbage behind the mark, empty and full lists, ragged R) with and without value
+    lists, and through the raw C ABI with a capacity below N: dropped entries, complete offsets."""
+    import ctypes
+    from lvmhelpers import _native
+    rng = np.random.default_rng(R * 7 + K * 3 + cap)
+    p = np.zeros((R, K), np.float32)
+    lists = np.full((R, cap), -1, np.int32)
+    vl = rng.random((R, cap)).astype(np.float32) * 0 - 7.0       # garbage where no column is listed
+    for r in range(R):
+        kind = r % 6
+        n = int(rng.integers(0, min(cap, K) + 1)) if kind not in (1, 4) else (min(cap, K) if kind == 1 else 0)
+        cols = rng.choice(K, n, replace=False)
+        if r % 3 == 2:
+            cols = rng.choice(K, int(rng.integers(1, K + 1)), replace=False)
+            lists[r] = rng.integers(-5, K, cap)
+            lists[r, 0] = -2 if r % 2 else -3
+        else:
+            lists[r, :n] = cols
+        p[r, cols] = rng.random(len(cols)).astype(np.float32) + 0.01
+        if r % 3 != 2:
+            vl[r, :n] = p[r, cols]
+    off_ref, rows_ref, cols_ref, vals_ref = oracle_mod.support_compact(p)
+    pt, lt, vt = torch.from_numpy(p).to(dev), torch.from_numpy(lists).to(dev), torch.from_numpy(vl).to(dev)
+    for sv in (None, vt):
+        off, rows, cols, vals = _native.support_compact_fused(pt, lt, sv, n_cap=R * K)
+        assert np.array_equal(off.cpu().numpy(), off_ref)
+        assert np.array_equal(rows.cpu().numpy(), rows_ref)
+        assert np.array_equal(cols.cpu().numpy(), cols_ref)
+        assert np.array_equal(vals.cpu().numpy(), vals_ref)
+    # raw ABI, capacity below N
+    L = _native.lib()
+    N = int(off_ref[-1])
+    ncap = max(N - 5, 0)
+    off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    rows = torch.full((ncap + 8,), -9, dtype=torch.int32, device=dev)
+    cols = torch.full((ncap + 8,), -9, dtype=torch.int32, device=dev)
+    vals = torch.full((ncap + 8,), -9.0, dtype=torch.float32, device=dev)
+    nb = L.smlvm_support_compact_fused_workspace_bytes(ctypes.c_int64(R))
+    ws = torch.full((nb // 8,), -1, dtype=torch.int64, device=dev)     # dirty: the call clears it
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = L.smlvm_support_compact_fused(P(pt), P(lt), P(vt), ctypes.c_int32(cap), P(off), P(rows), P(cols), P(vals),
+                                       ctypes.c_int64(ncap), ctypes.c_int64(R), ctypes.c_int32(K), P(ws),
+                                       ctypes.c_size_t(nb), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(off.cpu().numpy(), off_ref)
+    assert ws[1].item() == 0 and ws[2].item() == N
+    assert np.array_equal(rows[:ncap].cpu().numpy(), rows_ref[:ncap]) and bool((rows[ncap:] == -9).all())
+    assert np.array_equal(cols[:ncap].cpu().numpy(), cols_ref[:ncap]) and bool((cols[ncap:] == -9).all())
+    assert np.array_equal(vals[:ncap].cpu().numpy(), vals_ref[:ncap]) and bool((vals[ncap:] == -9).all())
+
+
 def test_support_tag_goes_stale_when_p_is_modified(dev):
     """The support lists ride on the probability tensor as a Python attribute; an in-place change of
     p afterwards must invalidate them (compaction would otherwise list the old support)."""
