@@ -102,6 +102,27 @@ def test_pbinary_topk_host_api(dev, oracle_mod):
         pbinary_topk.batched_topk(scores.astype(np.float64), cfg, 10)
 
 
+def test_binary_topk_kernel_on_the_reference_golden_vectors(dev):
+    """tests/golden/binary_topk.npz was produced by the reference's own binary_topk.h compiled in
+    place (oracle/_ref, tests/golden/make_goldens.py); every case that the kernel's limits admit
+    (k <= 64, n <= 512) goes straight to smlvm_binary_topk_batched: configurations and fp32 scores
+    bit for bit (lvmhelpers/binary_topk.h:57-129, pbinary_topk.pyx:23-34)."""
+    import os
+    from lvmhelpers import _native
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "binary_topk.npz"))
+    n_cases = int(d["n_cases"])
+    assert n_cases >= 10
+    for i in range(n_cases):
+        scores, k = d[f"scores_{i}"], int(d[f"k_{i}"])
+        cfg, top = _native.binary_topk_batched(torch.from_numpy(scores).to(dev), k, want_scores=True)
+        assert np.array_equal(cfg.cpu().numpy().astype(np.uint8), d[f"configs_{i}"]), i
+        assert np.array_equal(top.cpu().numpy(), d[f"top_{i}"]), i
+    # SURVEY.md 8(c)'s probe: binary_topk([0.5, -1, 2, 0.1], 5)
+    cfg, top = _native.binary_topk_batched(torch.tensor([[0.5, -1.0, 2.0, 0.1]], device=dev), 5, want_scores=True)
+    assert np.array_equal(cfg.cpu().numpy().astype(np.uint8), d["probe_configs"])
+    assert np.array_equal(top.cpu().numpy(), d["probe_top"])
+
+
 @pytest.mark.parametrize("R,K,sigma", [(64, 10, 1.0), (64, 256, 1.0), (300, 1000, 1.0), (64, 4096, 1.0),
                                        (64, 4096, 0.05), (20, 8192, 1.0), (9, 65536, 1.0),
                                        (128, 256, 0.05)])

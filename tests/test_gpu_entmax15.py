@@ -44,6 +44,27 @@ def test_fwd_bwd_match_oracle(dev, oracle_mod, R, K, sigma):
     assert np.abs(dx - dx_ref).max() <= 2e-5 * max(1.0, np.abs(dx_ref).max())
 
 
+@pytest.mark.parametrize("K,sigma", [(10, 1.0), (256, 1.0), (256, 3.0)])
+def test_support_against_the_oracle_on_a_million_rows(dev, oracle_mod, K, sigma):
+    """How many support elements differ from the oracle's (entmax15 is ExplicitWrapper's default
+    normaliser, lvmhelpers/marg.py:31-46, and its support drives Marginalizer's live columns):
+    counted over 2^20 random rows and STATED -- the kernel takes tau from an fp64 closed form, the
+    oracle from the package's fp32 sort/cumsum, so an element within an ulp of tau can fall on
+    either side in principle.  Measured (round 3): 0 of 5.3M / 14.9M / 4.0M support elements differ;
+    asserted: none on these (deterministic) inputs."""
+    from lvmhelpers import _native
+    R = 1 << 20
+    rng = np.random.default_rng(K + 17)
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    p_ref, nnz_ref, _ = oracle_mod.entmax15_fwd(x)
+    p = _native.entmax15_fwd(torch.from_numpy(x).to(dev))[0].cpu().numpy()
+    differ = (p > 0) != (p_ref > 0)
+    n_diff = int(differ.sum())
+    print(f"entmax15 K={K} sigma={sigma}: {n_diff} of {int((p_ref > 0).sum())} support elements differ over {R} rows")
+    assert n_diff == 0
+    assert np.abs(p - p_ref).max() <= 2e-6
+
+
 def test_autograd_and_module_paths(dev, oracle_mod):
     """functional.entmax15 / the entmax shim / ExplicitWrapper(normalizer='entmax') run the kernels;
     any `dim`; Entmax15Loss value and gradient."""

@@ -396,10 +396,17 @@ def test_mask_mark_follows_the_nonzero_count(dev, oracle_mod):
     p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
     assert np.array_equal(p.cpu().numpy(), p_ref) and np.array_equal(supp.cpu().numpy(), s_ref)
     assert np.all(cols[:, 0].cpu().numpy() == -3)
-    mask_garbage = torch.full_like(mask, -1)          # the same rows with an unwritten mask would gather junk
     dx = _native.sparsemax_bwd_cols(dyt, cols, p, supp, mask)
     assert torch.equal(dx, _native.sparsemax_bwd(dyt, p, supp))
-    del mask_garbage
+    # ... and it really comes from the mask: a masked row (<= 96 non-zeros) never reads p -- the
+    # same call with p replaced by NaNs gives the same dx --, while a mask that was NOT written for
+    # these rows (all bits set) gives something else
+    nnz = (p > 0).sum(1)
+    assert int(nnz.max()) <= 96
+    dx_nan_p = _native.sparsemax_bwd_cols(dyt, cols, torch.full_like(p, float("nan")), supp, mask)
+    assert torch.equal(dx_nan_p, dx)
+    dx_junk = _native.sparsemax_bwd_cols(dyt, cols, p, supp, torch.full_like(mask, -1))
+    assert not torch.equal(dx_junk, dx)
 
 
 @pytest.mark.parametrize("R,K", [(6, 5000), (5, 8192), (4, 50001), (7, 4097), (9, 3001), (64, 255)])
