@@ -602,6 +602,8 @@ def train_steps_bench(dev, world, rank):
         del m, b
     # cfg5: global batch 8192 over 8 GPUs = 1024 per rank, one flat-bucket RCCL all-reduce per step
     m, b = bm.make_bitvae(dev, 1024, 128, "sparsemap", seed=0)
+    if _dist_on():
+        m.encoder.shard = "auto"   # init scores from the global-batch stream (every rank seeds alike)
     res["cfg5_bitvae_sparsemap_128bits_b1024_per_gpu"] = run(m, b, 1024, steps=5, warm=3)
     res["cfg5_bitvae_sparsemap_128bits_b1024_per_gpu"]["grad_allreduce"] = (
         f"1 bucket of {sum(p.numel() for p in m.parameters()) * 4 / 1e6:.1f} MB over {world} rank(s)")

@@ -139,7 +139,9 @@ int smlvm_support_compact(const float* p, const int64_t* row_offsets, int32_t* r
  * smlvm_support_offsets, bit for bit.  Nothing is allocated or freed inside (the first call on a
  * device looks the array's address up once, with that device current).  Every call on one GPU
  * uses that GPU's one array: calls that overlap on the same GPU (two streams) race -- serialise
- * them, or use smlvm_support_offsets with a workspace per stream. */
+ * them, or use smlvm_support_offsets with a workspace per stream.  The stream's GPU must be the
+ * current device of the calling thread (as for every launch here); a stream of another GPU is
+ * refused with SMLVM_ERR_INVALID rather than handed the current GPU's array. */
 #define SMLVM_NOALLOC_MAX_ROWS (1 << 24)
 int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_offsets, int64_t R, void* stream);
 /* The same two steps from the forward's support lists (smlvm_sparsemax_fwd_cols): rows that have

@@ -914,10 +914,20 @@ constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mutex;
 static long long* g_scratch_ptr[kMaxDevices];   // per device: each GPU holds its own copy of the array
 
-static long long* offsets_scratch_on_current_device()
+// The array of the GPU the launches will run on: the stream's device when the stream knows it
+// (a stream of another GPU than the current one must not get the current GPU's array), the
+// current device for the null stream.  The symbol's address is looked up with that device current.
+static long long* offsets_scratch_for_stream(hipStream_t st, int* mismatch)
 {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    int cur = -1, dev = -1;
+    *mismatch = 0;
+    if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= kMaxDevices) return nullptr;
+    dev = cur;
+    if (st != nullptr) {
+        int sdev = -1;
+        if (hipStreamGetDevice(st, &sdev) == hipSuccess && sdev >= 0 && sdev < kMaxDevices) dev = sdev;
+    }
+    if (dev != cur) { *mismatch = 1; return nullptr; }   // launches go to the current device: refuse
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         void* ptr = nullptr;
@@ -942,7 +952,9 @@ extern "C" int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_of
         return SMLVM_OK;
     }
     if (!nnz) return SMLVM_ERR_INVALID;
-    long long* sums = offsets_scratch_on_current_device();
+    int mismatch = 0;
+    long long* sums = offsets_scratch_for_stream(st, &mismatch);
+    if (mismatch) return SMLVM_ERR_INVALID;   // the stream belongs to another GPU than the current one
     if (!sums) return SMLVM_ERR_HIP;
     // every block sum the later launches read is written by the first one: nothing has to be cleared
     const int64_t nblocks = (R + kScanItemsPerBlock - 1) / kScanItemsPerBlock;

@@ -116,6 +116,12 @@ class Marginalizer(torch.nn.Module):
             if dim is None:
                 return t
             if isinstance(t, (list, tuple)):   # a list of per-slot tensors counts as axis 0
+                if dim < 1:
+                    raise ValueError(
+                        "Marginalizer(compact=True): a list/tuple input counts as axis 0 (one entry "
+                        "per slot), so its batch axis must be >= 1 -- e.g. batch_dims=(None, 1) or "
+                        "LVMHELPERS_BATCH_DIMS=\"none,1\" for the signal game's [game_size][B, feat] "
+                        f"receiver input; got batch axis {dim}")
                 return type(t)(take(e, dim - 1) for e in t)
             return t.index_select(dim, rows_l)
 

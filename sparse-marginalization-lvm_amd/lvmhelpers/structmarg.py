@@ -117,8 +117,10 @@ class SparseMAPWrapper(nn.Module):
         self.init = init
         self.max_iter = max_iter
         self._idx_tensor = None
-        # Data-parallel runs: (rank, world, batch_total) of the shard this module sees.  None = ask
-        # torch.distributed (equal shards), or the whole batch when it is not initialised.
+        # Data-parallel runs (opt-in): (rank, world, batch_total) of the shard this module sees, or
+        # "auto" = ask torch.distributed (equal shards, same CPU seed on every rank -- the caller's
+        # responsibility).  None (default) = the reference's draw: torch.rand(2n) per local sample
+        # from this process's CPU generator, whatever torch.distributed is used for.
         self.shard = None
 
     def _init_scores(self, batch_size, latent_size, device):
@@ -127,7 +129,7 @@ class SparseMAPWrapper(nn.Module):
         # ranks, every rank draws the block of the GLOBAL batch (same seed -> same stream) and
         # keeps its rows, so a sample's init scores -- hence its active set -- do not depend on
         # the world size.
-        shard = self.shard if self.shard is not None else dataparallel.current_shard(batch_size)
+        shard = dataparallel.current_shard(batch_size) if self.shard == "auto" else self.shard
         if shard is None:
             return torch.rand(batch_size, 2 * latent_size, dtype=torch.double).to(device)
         rank, world, batch_total = shard

@@ -92,6 +92,22 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_sparsemax_support_mask_bytes(i64(10), i32(4100)) == 0
     assert lib.smlvm_support_compact_cols(null, null, i32(0), null, null, null, null, i64(0), i32(4), null) == 0
     assert lib.smlvm_support_compact_cols(one, one, i32(65), one, null, null, null, i64(3), i32(4), null) == -1
+    # the 128-slot lists the forward can write for K > 4096 feed the backward only (header)
+    assert lib.smlvm_support_count_cols(one, one, i32(128), one, i64(3), i32(8192), null) == -1
+    assert lib.smlvm_support_compact_cols(one, one, i32(128), one, null, null, null, i64(3), i32(8192), null) == -1
+    # the single-pass compaction: argument checks only (no launch without a GPU)
+    lib.smlvm_support_compact_fused_workspace_bytes.restype = ctypes.c_size_t
+    lib.smlvm_support_compact_fused_workspace_bytes.argtypes = [ctypes.c_int64]
+    assert lib.smlvm_support_compact_fused_workspace_bytes(0) == 32
+    assert lib.smlvm_support_compact_fused_workspace_bytes(513) == 8 * (4 + 2)
+    fused = lib.smlvm_support_compact_fused
+    sz = ctypes.c_size_t
+    assert fused(one, one, null, i32(48), one, null, null, null, i64(0), i64(3), i32(4), one, sz(1 << 20), null) == -1   # cap
+    assert fused(one, null, one, i32(0), one, null, null, null, i64(0), i64(3), i32(4), one, sz(1 << 20), null) == -1    # vals without cols
+    assert fused(one, null, null, i32(0), null, null, null, null, i64(0), i64(3), i32(4), one, sz(1 << 20), null) == -1  # no offsets
+    assert fused(one, null, null, i32(0), one, null, null, null, i64(0), i64(3), i32(4), null, sz(0), null) == -4        # no workspace
+    assert lib.smlvm_sparsemax_fwd_lists(one, one, one, null, null, null, one, one, i32(32), null, i64(3), i32(8192), null) == -2
+    assert lib.smlvm_sparsemax_fwd_lists(one, one, one, null, null, null, null, one, i32(32), null, i64(3), i32(64), null) == -1
     assert lib.smlvm_support_count_cols(one, one, i32(0), one, i64(3), i32(4), null) == -1
     assert lib.smlvm_support_count_cols(null, null, i32(0), null, i64(3), i32(4), null) == -1
     lib.smlvm_support_offsets_workspace_bytes.restype = ctypes.c_size_t

@@ -368,6 +368,21 @@ def test_marginalizer_compact_equals_dense(dev, K, coeff):
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
 
 
+def test_compact_mode_refuses_a_list_input_on_batch_axis_0(dev):
+    """A list/tuple decoder input is one entry per slot (axis 0); with the default batch_dims (0, 0)
+    the support-only mode used to gather the FEATURE axis of every entry with row indices.  It now
+    raises and names the setting the signal game needs."""
+    import bench_models as bm
+    from lvmhelpers.marg import Marginalizer
+    model, (x, recv, labels) = bm.make_signal_game(dev, 64, compact=True, hoist=False)
+    model.batch_dims = (0, 0)
+    recv_list = [recv[i] for i in range(recv.shape[0])]
+    with pytest.raises(ValueError, match="none,1"):
+        model(x, recv_list, labels)
+    model.batch_dims = (None, 1)
+    assert torch.isfinite(model(x, recv_list, labels)["loss"])
+
+
 def _signal_game_run(dev, compact, hoist, list_input=False):
     import bench_models as bm
     model, (x, recv, labels) = bm.make_signal_game(dev, 64, compact=compact, hoist=hoist)
