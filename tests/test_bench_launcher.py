@@ -51,3 +51,26 @@ def test_parent_relays_the_line_and_the_exit_code(tmp_path, monkeypatch):
         monkeypatch.setattr(bench, "child_command",
                             lambda g, argv, port, c=code, n=n: [sys.executable, str(fake), str(n), str(c)])
         assert bench.launch_ranks(A(), []) == expect
+
+
+def test_strong_scaling_inputs_are_a_function_of_the_global_row():
+    """`bench.py --scaling strong`: rows come from generators seeded per chunk of global rows, so any
+    split of [0, R) reproduces the same values, and the wrapping-int64 checksum is additive over
+    the shards (what lets rank 0 compare the N-GPU job's checksums with the 1-GPU run's)."""
+    import torch
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "sparse-marginalization-lvm_amd"))
+    from lvmhelpers import dataparallel
+    dev = torch.device("cpu")
+    R, K, chunk = 1000, 12, 64
+    x, dy = bench.gen_by_global_row(0, R, K, 0.7, dev, seed=5, chunk=chunk)
+    for world in (1, 2, 3, 8):
+        parts = [bench.gen_by_global_row(*dataparallel.shard_range(R, r, world), K, 0.7, dev, seed=5, chunk=chunk)
+                 for r in range(world)]
+        assert torch.equal(torch.cat([p[0] for p in parts]), x)
+        assert torch.equal(torch.cat([p[1] for p in parts]), dy)
+        total = sum(bench.checksum64(p[0]) for p in parts)
+        wrap = (total + 2 ** 63) % 2 ** 64 - 2 ** 63
+        assert wrap == bench.checksum64(x)
+    e, _ = bench.gen_by_global_row(10, 10, K, 0.7, dev, seed=5, chunk=chunk)
+    assert e.shape == (0, K)

@@ -134,3 +134,40 @@ def test_shard_ranges_cover_and_partition():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _worker_strong(rank, world, port, out):
+    """bench.py's strong-scaling logic on CPU tensors: rows by global index, contiguous shards, the
+    job's checksums as a wrapping int64 all-reduce over the ranks."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from lvmhelpers import dataparallel as dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, K = 777, 20
+    lo, hi = dp.shard_range(R, rank, world)
+    x, dy = bench.gen_by_global_row(lo, hi, K, 1.0, torch.device("cpu"), seed=9, chunk=100)
+    sums = bench.sum_over_ranks_i64([bench.checksum64(x), bench.checksum64(dy)], torch.device("cpu"))
+    if rank == 0:
+        out.put(sums)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_checksums_over_two_ranks_equal_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sums = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    x, dy = bench.gen_by_global_row(0, 777, 20, 1.0, torch.device("cpu"), seed=9, chunk=100)
+    assert sums == [bench.checksum64(x), bench.checksum64(dy)]
