@@ -262,12 +262,15 @@ FUSED_SMALL = 1 << 22       # R * K up to which the bound is simply R * K
 
 
 def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=True, want_cols=True,
-                          want_vals=True, n_cap=None):
+                          want_vals=True, n_cap=None, host_offsets=False):
     """Count + offsets + compaction in ONE launch (smlvm_support_compact_fused) and one host sync
     (N).  The outputs are sized by an upper bound on N -- R * cap when the rows have lists, R * K
     for small matrices -- and returned as views of length N; should N exceed the bound (rows
     without a list in a list-fed call) the entries are redone from the offsets.  Returns
-    (row_offsets, rows, cols, vals) like support_compact, or None when no affordable bound exists."""
+    (row_offsets, rows, cols, vals) like support_compact, or None when no affordable bound exists.
+    host_offsets=True appends the offsets as a host numpy array, read back in the SAME transfer as
+    N (the callers that need per-row counts on the host -- SparseMAPWrapper's `support` / `idxs`
+    lists -- then pay one device-to-host copy per step instead of two)."""
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     dev = p.device
@@ -293,27 +296,33 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
             n_cap = R * min(K, 2 * cap)
         if n_cap > FUSED_MAX_BOUND:
             return None
-    off = torch.empty(R + 1, dtype=torch.int64, device=dev)
+    nbytes = lib().smlvm_support_compact_fused_workspace_bytes(_i64(R))
+    both = torch.empty(nbytes // 8 + R + 1, dtype=torch.int64, device=dev)   # workspace | offsets
+    ws, off = both[:nbytes // 8], both[nbytes // 8:]
     rows = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_rows else None
     cols = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_cols else None
     vals = torch.empty(n_cap, dtype=torch.float32, device=dev) if want_vals else None
-    nbytes = lib().smlvm_support_compact_fused_workspace_bytes(_i64(R))
-    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
                                                  _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
                                                  _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
                                                  _stream()), "smlvm_support_compact_fused")
     if R == 0:
-        return off, rows, cols, vals
-    err, N = (int(v) for v in ws[1:3].tolist())          # the one host sync
+        return (off, rows, cols, vals) + ((off.cpu().numpy(),) if host_offsets else ())
+    off_h = None
+    if host_offsets:
+        both_h = both.cpu().numpy()                        # the one host sync: flags, N and the offsets
+        err, N, off_h = int(both_h[1]), int(both_h[2]), both_h[nbytes // 8:]
+    else:
+        err, N = (int(v) for v in ws[1:3].tolist())        # the one host sync
     if err:
         raise NativeError("smlvm_support_compact_fused: a tile gave up waiting for the tiles before it")
+    extra = (off_h,) if host_offsets else ()
     if N > n_cap:   # rows without a list overflowed the bound: the entries again, from the offsets
         return support_compact(p, want_rows=want_rows, want_cols=want_cols, want_vals=want_vals,
-                               support_cols=support_cols, row_offsets=off, total=N, fused=False)
+                               support_cols=support_cols, row_offsets=off, total=N, fused=False) + extra
     cut = lambda t: None if t is None else t[:N]
-    return off, cut(rows), cut(cols), cut(vals)
+    return (off, cut(rows), cut(cols), cut(vals)) + extra
 
 
 def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None,

@@ -123,6 +123,10 @@ class Marginalizer(torch.nn.Module):
                         "LVMHELPERS_BATCH_DIMS=\"none,1\" for the signal game's [game_size][B, feat] "
                         f"receiver input; got batch axis {dim}")
                 return type(t)(take(e, dim - 1) for e in t)
+            if t.shape[dim] != batch_size:   # (a gather with out-of-range rows faults the GPU)
+                raise ValueError(
+                    f"Marginalizer(compact=True): axis {dim} of an input of shape {tuple(t.shape)} is "
+                    f"not the batch axis (batch size {batch_size}); set batch_dims / LVMHELPERS_BATCH_DIMS")
             return t.index_select(dim, rows_l)
 
         encoder_input_sel = take(encoder_input, self.batch_dims[0])

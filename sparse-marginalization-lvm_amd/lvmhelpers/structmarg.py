@@ -150,15 +150,19 @@ class SparseMAPWrapper(nn.Module):
         # one read-back per step: the row offsets.  N, `support` and `idxs` (row b repeated
         # support[b] times: the compaction is in row-major order) follow from them on the host,
         # while the compaction itself runs on the device.
-        lists = F_.support_cols_of(p)
-        off = _native.support_row_offsets(p.detach(), support_cols=lists)
-        off_h = off.cpu().numpy()
+        # (count + offsets + compaction are one launch; N and the offsets come back in one copy)
+        fused = _native.support_compact_fused(p.detach(), want_vals=False, host_offsets=True)
+        if fused is None:   # a batch too large for the single-pass bound: separate launches
+            off = _native.support_row_offsets(p.detach())
+            off_h = off.cpu().numpy()
+            _, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, row_offsets=off,
+                                                       total=int(off_h[-1]), fused=False)
+        else:
+            _, rows, cols, _, off_h = fused
         counts = np.diff(off_h)
         support = counts.tolist()
         assert min(support) > 0
         idxs = np.repeat(np.arange(batch_size), counts).tolist()
-        _, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, support_cols=lists,
-                                                   row_offsets=off, total=int(off_h[-1]))
         rows_l = rows.long()
         sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
         distr = p[rows_l, cols.long()]

@@ -375,9 +375,14 @@ def test_compact_mode_refuses_a_list_input_on_batch_axis_0(dev):
     import bench_models as bm
     from lvmhelpers.marg import Marginalizer
     model, (x, recv, labels) = bm.make_signal_game(dev, 64, compact=True, hoist=False)
-    model.batch_dims = (0, 0)
     recv_list = [recv[i] for i in range(recv.shape[0])]
+    model.batch_dims = (None, 0)
     with pytest.raises(ValueError, match="none,1"):
+        model(x, recv_list, labels)
+    # an axis that is not the batch axis is refused on the host (x is [game_size, B, feat]: axis 0
+    # has 16 entries, the rows go up to 63 -- gathering it would read out of bounds on the GPU)
+    model.batch_dims = (0, 1)
+    with pytest.raises(ValueError, match="not the batch axis"):
         model(x, recv_list, labels)
     model.batch_dims = (None, 1)
     assert torch.isfinite(model(x, recv_list, labels)["loss"])
