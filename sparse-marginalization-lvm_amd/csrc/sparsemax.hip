@@ -260,6 +260,40 @@ __device__ __forceinline__ int classify_group(int m_gt, double S_gt, float v, in
     return d > B ? 1 : (d < -B ? -1 : 0);
 }
 
+// Exponent of the lowest set bit of a finite, non-zero double (x is an odd multiple of 2^that).
+__device__ __forceinline__ int lsb_exp_f64(double x)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    int e = (int)((b >> 52) & 0x7ffull);
+    unsigned long long m = b & ((1ull << 52) - 1ull);
+    if (e != 0) m |= 1ull << 52; else e = 1;
+    return e - 1075 + __builtin_ctzll(m);
+}
+
+// True when every fp32 / fp64 operation of cond_rank(m_gt, S_gt, v, r), r = 1..t, is EXACT: v, S_gt
+// and 1 are multiples of one power of two 2^q (q <= 0) and every intermediate -- (float)j, j v,
+// S_gt + r v, (float)S, (float)S - 1 -- is a multiple of 2^q below 2^(24+q) in magnitude, hence
+// representable in fp32.  Then the test at every rank of the group is the exact inequality
+// (m_gt + r) v > S_gt + r v - 1, i.e. m_gt v - S_gt + 1 > 0, the same for all r: the group passes
+// or fails as a whole and nothing has to be counted rank by rank (round 3: integer- and
+// dyadic-valued rows -- the "exact tie at the threshold" rows of SURVEY.md 8(d) S1 -- used to run
+// up to 65535 rank tests per row).
+__device__ __forceinline__ bool tie_group_is_exact(int m_gt, double S_gt, float v, int t)
+{
+    int q = 0;
+    if (v != 0.0f) { const int e = lsb_exp_f64((double)v); q = e < q ? e : q; }
+    if (S_gt != 0.0) { const int e = lsb_exp_f64(S_gt); q = e < q ? e : q; }
+    if (q < -900 || m_gt + t >= (1 << 24)) return false;
+    const double lim = __builtin_bit_cast(double, (unsigned long long)(1023 + 24 + q) << 52);   // 2^(24+q)
+    const double av = fabs((double)v);
+    return (double)(m_gt + t) * av < lim && fabs(S_gt) + (double)t * av + 1.0 < lim;
+}
+// number of ranks of an undecided group whose test holds, when tie_group_is_exact
+__device__ __forceinline__ int exact_tie_count(int m_gt, double S_gt, float v, int t)
+{
+    return ((double)m_gt * (double)v - S_gt + 1.0 > 0.0) ? t : 0;
+}
+
 // every rank below (m, S), whose largest value is vnext, fails robustly (nvis >= ranks in sight)
 __device__ __forceinline__ bool deeper_all_fail(int m, double S_m, float vnext, int nvis)
 {
@@ -389,8 +423,10 @@ __device__ __forceinline__ void solve_edge(const Src& src, Red& red, float tau, 
         const Edge g = edge_pass(src, vnext, red);
         const int k = classify_group(g.m_gt, g.S_gt, vnext, g.t);
         int cnt = k > 0 ? g.t : 0;
-        if (__builtin_expect(k == 0, 0))
-            cnt = red.sum(count_ranks_part(g.m_gt, g.S_gt, vnext, g.t, red.idx(), red.stride()));
+        if (__builtin_expect(k == 0, 0)) {
+            if (tie_group_is_exact(g.m_gt, g.S_gt, vnext, g.t)) cnt = exact_tie_count(g.m_gt, g.S_gt, vnext, g.t);
+            else cnt = red.sum(count_ranks_part(g.m_gt, g.S_gt, vnext, g.t, red.idx(), red.stride()));
+        }
         if (open) {
             S_at = g.S_gt + (double)cnt * (double)vnext;
             open = cnt == g.t;
@@ -678,6 +714,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
     // stopped AT Michelot's fixed point (then the search starts with the edge, no iteration)
     float full_tau = -1.0f;
     bool full_fixed = false;
+    bool solved = false;   // s_final / S_final already hold the answer (few-valued rows, NW > 1)
     if constexpr (CAND) {   // K <= 65536 < kCandMaxK in every kernel that comes through here
         const int lane = threadIdx.x & 63;
         float c[kCandPerLane];
@@ -795,10 +832,76 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     // and no workgroup barrier (the workgroup-wide version of this loop cost a
                     // barrier per step, 5-6 of them per row).
                     first = false;
+                    WaveRed<64> wred;
+                    // Rows made of ONE or TWO distinct values (all-equal rows; one dominant value
+                    // over a plateau within 1 of it: SURVEY.md 8(d) S1's adversarial rows) have a
+                    // closed form and need no search.  Noticed here for free: their lane maxima take
+                    // at most two values.  Verified on the registers (row minimum, then the counts of
+                    // 0, of the minimum and of the finite elements: two passes, two barriers) -- only
+                    // for such rows.  (One pass with the lane maxima's second value as the minimum
+                    // was measured: all-equal rows 3.98 -> 3.87 ms, but the register allocation of
+                    // the common path moved and N(0,1) rows went 3.20 -> 3.31 ms; not kept.)
+                    // (Kept narrow on purpose -- the lane maxima are re-read from LDS, the three
+                    // counts travel as one double: this kernel sits at its 128-register limit.)
+                    {
+                        float mnv = INFINITY;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            const float t = lmx[w * 64 + lane];
+                            mnv = (t > -INFINITY) ? fminf(mnv, t) : mnv;
+                        }
+                        mnv = wred.min(mnv);
+                        int others = 0;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            const float t = lmx[w * 64 + lane];
+                            others += (t > -INFINITY && t != 0.0f && t != mnv) ? 1 : 0;
+                        }
+                        others = wred.sum(others);
+                        if (__builtin_amdgcn_readfirstlane(others) == 0) {   // same bits in every wave
+                            float lmn = INFINITY;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                float ze = z[e];
+                                asm volatile("" : "+v"(ze));
+                                lmn = (ze > -INFINITY) ? fminf(lmn, ze) : lmn;
+                            }
+                            const float rmin = red.min(lmn);
+                            int c0 = 0, cm = 0, cf = 0;
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                float ze = z[e];
+                                asm volatile("" : "+v"(ze));   // (see RegSrc: keeps the compare masks short-lived)
+                                c0 += ze == 0.0f ? 1 : 0;
+                                cm += ze == rmin ? 1 : 0;
+                                cf += ze > -INFINITY ? 1 : 0;
+                            }
+                            // zeros + 2^18 (elements at rmin) + 2^36 (finite elements): K <= 65536
+                            const double packed = (double)((long long)c0 + ((long long)cm << 18) + ((long long)cf << 36));
+                            const long long pk = (long long)red.sum(packed);
+                            const int n0 = (int)(pk & 0x3ffffll), nm = (int)((pk >> 18) & 0x3ffffll);
+                            const int fin = (int)(pk >> 36);
+                            if (rmin == 0.0f) {            // the row's minimum is its maximum: all equal,
+                                s_final = fin;             // every rank passes, S = 0
+                                S_final = 0.0;
+                                solved = true;
+                            } else if (n0 + nm == fin) {   // n0 zeros on top of a tie group of nm at rmin
+                                const int k = classify_group(n0, 0.0, rmin, nm);
+                                int cnt = k > 0 ? nm : 0;
+                                if (k == 0) {
+                                    if (tie_group_is_exact(n0, 0.0, rmin, nm)) cnt = exact_tie_count(n0, 0.0, rmin, nm);
+                                    else cnt = red.sum(count_ranks_part(n0, 0.0, rmin, nm, red.idx(), red.stride()));
+                                }
+                                s_final = n0 + cnt;
+                                S_final = (double)cnt * (double)rmin;
+                                solved = true;
+                            }
+                            if (solved) break;
+                        }
+                    }
                     float v[NW];
 #pragma unroll
                     for (int w = 0; w < NW; ++w) v[w] = lmx[w * 64 + lane];
-                    WaveRed<64> wred;
                     tau = -1.0f;
                     for (int cp = 0x7fffffff;;) {
                         int cn = 0;
@@ -854,7 +957,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
             }
         }
     }
-    if (__builtin_expect(!fast, 0)) solve_core(z, red, K, s_final, S_final, nullptr, full_tau, full_fixed);
+    if (__builtin_expect(!fast && !solved, 0)) solve_core(z, red, K, s_final, S_final, nullptr, full_tau, full_fixed);
 
     float c_s = (float)S_final - 1.0f;
     float tau_f = c_s / (float)s_final;

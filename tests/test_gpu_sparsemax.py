@@ -362,6 +362,60 @@ def test_tie_groups_at_threshold(dev, oracle_mod, K):
         assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 2e-6 * scale)
 
 
+@pytest.mark.parametrize("K", [256, 1000, 4096, 5000, 8192, 16384, 50001, 65536])
+def test_few_valued_rows_and_exact_tie_groups(dev, oracle_mod, K):
+    """Round 3 shortcuts of the threshold search, bit for bit against the oracle:
+      * tie groups whose rank tests are exact in fp32 (integer / dyadic values: the group passes or
+        fails as a whole, nothing is counted rank by rank) next to groups that are NOT exact
+        (values off a dyadic grid by an ulp, long groups whose sums leave the 24-bit range);
+      * rows made of one or two distinct values (closed form in the workgroup kernels, K > 4096)
+        and the rows that only look like them: every lane holds a zero but other values exist, a
+        third value below the plateau, -inf entries, plateaus at and around 1 below the maximum."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(K + 5)
+    f32 = np.float32
+    rows = []
+
+    def two_valued(a, v, base=0.0):
+        x = np.full(K, f32(base + v), f32)
+        x[rng.choice(K, a, replace=False)] = f32(base)
+        return x
+
+    for v in (-1.0, -0.5, -0.25, -0.75, -1.0 + 2 ** -20, -1.0 - 2 ** -20, -0.999, -1e-3, -2.0, -1.0 / 3, -2 ** -10):
+        for a in (1, 2, 3, 7, min(64, K - 1), K // 2, K - 1):
+            rows.append(two_valued(a, v))
+    rows.append(two_valued(1, -1.0, base=3.0))
+    rows.append(two_valued(1, -1.0, base=-7.25))
+    rows.append(np.full(K, f32(0.25), f32))                       # all equal
+    rows.append(np.full(K, f32(-3.0), f32))
+    x = np.zeros(K, f32); x[1::2] = -0.5; x[3] = -0.75; rows.append(x)                 # a third value
+    x = two_valued(1, -1.0); x[K // 3] = f32(-1.5); rows.append(x)                     # ... below the plateau
+    x = two_valued(5, -1.0); x[K // 2] = -np.inf; rows.append(x)                       # -inf entry
+    x = np.full(K, f32(0.0), f32); x[K - 1] = -np.inf; rows.append(x)
+    x = np.zeros(K, f32); x[rng.choice(K, K // 2, replace=False)] = f32(-1e-4); rows.append(x)
+    # exact and inexact tie groups under a few distinct larger values (the wave kernels' edge walk)
+    for v, top in ((-0.5, (0.0, -0.125)), (-0.25, (0.0,)), (-0.375, (0.0, -0.25, -0.3125)), (-0.3, (0.0, -0.1))):
+        x = np.full(K, f32(v), f32)
+        x[:len(top)] = np.array(top, f32)
+        rows.append(rng.permutation(x))
+    x = np.stack(rows)
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    xt = torch.from_numpy(x).to(dev)
+    p, supp, nnz, tau, _, cols, mask = _native.sparsemax_fwd(xt, want_nnz=True, want_tau=True, want_cols=True,
+                                                             want_mask=True)
+    bad = np.flatnonzero(supp.cpu().numpy() != s_ref)
+    assert bad.size == 0, (bad[:8], supp.cpu().numpy()[bad[:8]], s_ref[bad[:8]])
+    assert np.array_equal(tau.cpu().numpy(), tau_ref)
+    assert np.array_equal(p.cpu().numpy(), p_ref)
+    assert np.array_equal(nnz.cpu().numpy(), nnz_ref)
+    p2, supp2, _, _, _ = _native.sparsemax_fwd(xt)
+    assert np.array_equal(p2.cpu().numpy(), p_ref) and np.array_equal(supp2.cpu().numpy(), s_ref)
+    dy = rng.standard_normal(x.shape).astype(np.float32)
+    dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+    dxt = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp, mask)
+    assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 2e-6 * np.abs(dy).max(axis=1, keepdims=True))
+
+
 def test_mask_mark_follows_the_nonzero_count(dev, oracle_mod):
     """A row is marked -3 (support mask) exactly when #{p > 0} exceeds the list capacity; the
     oracle's supp_size can be smaller than that count when a tie group straddles the threshold
