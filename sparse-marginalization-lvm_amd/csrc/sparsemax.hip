@@ -788,7 +788,8 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 // (nor does it try the same cut twice)
                 const bool crowded = __ballot(lane_mx > thr) == ~0ull || !(thr > thr_tried);
                 thr_tried = thr;
-                const int n_w = crowded ? 65
+                // (a wave in which no lane's maximum is above the cut has nothing to compact)
+                const int n_w = crowded ? 65 : (__ballot(lane_mx > thr) == 0ull) ? 0
                                         : compact_candidates<E, VEC>(z, thr, cand + wave * 64, 64,
                                                                      ccols ? ccols + wave * 64 : nullptr,
                                                                      VEC ? (int)threadIdx.x * 4 : (int)threadIdx.x,
@@ -824,6 +825,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 }
                 __syncthreads();  // the lists are rewritten by the next attempt / the next row
                 if (fast) { thr_used = thr; tau_used = tau; break; }
+                if (solved) break;   // (the list of a solved row did not fit: it goes without)
                 if (first) {
                     // first failure: the threshold of the subset made of all 64 NW lane maxima is a
                     // lower bound of the row's.  Every wave runs that Michelot iteration on its own
@@ -895,6 +897,16 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                                 s_final = n0 + cnt;
                                 S_final = (double)cnt * (double)rmin;
                                 solved = true;
+                                // the plateau stays out and the support is a handful of zeros: one
+                                // more turn of this loop compacts them (the elements above rmin)
+                                // into the candidate lists, only so that the row gets its support
+                                // list and its backward does not have to read p
+                                // (only if the plateau's p is exactly 0 -- the epilogue's own
+                                // expression -- so that the zeros are ALL the non-zeros of p)
+                                if (list && cnt == 0 && n0 <= 64 && !(rmin - (-1.0f / (float)n0) > 0.0f)) {
+                                    thr = rmin;
+                                    continue;
+                                }
                             }
                             if (solved) break;
                         }
@@ -942,7 +954,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 thr = fmaxf(tau - margin, floor_k);
             }
         }
-        if (fast) {
+        if (fast && !solved) {
             WaveRed<64> wred;  // every wave solves the same small problem: no barriers
             int m_robust = 0;
             solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
