@@ -1016,7 +1016,18 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     // the group's lanes: the per-element cost is a compare and an add (a wave-wide ballot per
     // element with the group's bits picked out of it cost three times as much, and these tiles are
     // instruction bound).  Nothing is written unless the lists fit.
-    auto compact_above = [&](float thr) -> bool {
+    // Rows solved in closed form (few-valued rows, below) keep out of the lists: they show the
+    // compaction their own cut thr_closed -- the plateau's value when the support is the handful of
+    // zeros above it (the list is wanted for the support list), +inf otherwise -- and a row that
+    // shows nothing gets one stand-in candidate (0 at column 0) so that the search on the lists has
+    // a well-formed row to chew on; its result is replaced by the closed form.
+    // (Their closed form waits in LDS, five words per lane behind the wave's lists: carried in
+    // registers across the search it cost the common path 6 more spills and 8 % of its time.)
+    bool closed = false;
+    float* stash = cand + 2 * kCandCap + (threadIdx.x & 63);   // [k * 64]: thr, s, n, S lo, S hi
+    auto compact_above = [&](float thr_all) -> bool {
+        float thr = thr_all;
+        if (__ballot(closed) != 0ull) thr = closed ? stash[0] : thr_all;
         int mine = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) mine += z[e] > thr ? 1 : 0;
@@ -1042,6 +1053,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             c[q] = have ? clist[gl + G * q] : -INFINITY;
             cc[q] = (have && list) ? ccols[gl + G * q] : 0;
         }
+        if (closed && total == 0 && gl == 0) c[0] = 0.0f;
         wave_lds_sync();
         return true;
     };
@@ -1051,7 +1063,71 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     float tau = -1.0f, thr_used = floor_k, tau_used = -1.0f;
     bool all_fixed = false;   // wave-uniform: the Michelot iteration below has converged for every row
     bool fast = compact_above(floor_k);
-    if (!fast) {
+    if (__builtin_expect(!fast, 0)) {
+        // Rows made of ONE or TWO distinct values (all-equal rows; a few zeros over a plateau: the
+        // adversarial rows of SURVEY.md 8(d) S1) have a closed form; left in, one such row sends
+        // the other rows of its wave to the full-width search as well (a quarter of such rows among
+        // N(0,1) rows at K = 256: 0.61 ms against 0.37-0.49 ms for any one kind alone).  Their lane
+        // maxima take at most two values, which costs two group reductions to see; only then are
+        // the registers counted (minimum; zeros, elements at the minimum, finite elements).
+        const bool fin_l = lane_mx > -INFINITY;
+        const float lmin = red.min(fin_l ? lane_mx : INFINITY);
+        const int others = red.sum((fin_l && lane_mx != 0.0f && lane_mx != lmin) ? 1 : 0);
+        if (__ballot(others == 0) != 0ull) {   // wave-uniform
+            float lmn = INFINITY;
+#pragma unroll
+            for (int e = 0; e < E; ++e) lmn = (z[e] > -INFINITY) ? fminf(lmn, z[e]) : lmn;
+            const float rmin = red.min(lmn);
+            int pk = 0;   // zeros + 2^10 (elements at rmin) + 2^20 (finite elements): K <= 512
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                pk += (z[e] == 0.0f ? 1 : 0) + (z[e] == rmin ? 1 << 10 : 0) + (z[e] > -INFINITY ? 1 << 20 : 0);
+            pk = red.sum(pk);
+            const int n0 = pk & 1023, nm = (pk >> 10) & 1023, fin = pk >> 20;
+            const bool one = rmin == 0.0f;                    // the minimum is the maximum
+            const bool two = !one && n0 + nm == fin;          // n0 zeros over a tie group of nm at rmin
+            int cnt = 0;
+            bool open = false;
+            if (two) {
+                const int k = classify_group(n0, 0.0, rmin, nm);
+                cnt = k > 0 ? nm : 0;
+                if (k == 0) {
+                    if (tie_group_is_exact(n0, 0.0, rmin, nm)) cnt = exact_tie_count(n0, 0.0, rmin, nm);
+                    else open = true;
+                }
+            }
+            if (__ballot(open) != 0ull) {   // ranks inside the rounding band: counted by the row's lanes
+                const int part = red.sum(open ? count_ranks_part(n0, 0.0, rmin, nm, gl, G) : 0);
+                if (open) cnt = part;
+            }
+            int s_closed = 1, n_closed = 0;
+            double S_closed = 0.0;
+            float thr_closed = INFINITY;
+            if (one) {
+                s_closed = fin;   // every rank passes, S = 0, p = 1/K everywhere
+                n_closed = fin;
+            } else if (two) {
+                s_closed = n0 + cnt;
+                S_closed = (double)cnt * (double)rmin;
+                // the plateau's p, by the epilogue's own expression
+                const float pv = rmin - ((float)S_closed - 1.0f) / (float)s_closed;
+                n_closed = n0 + (pv > 0.0f ? nm : 0);
+                if (!(pv > 0.0f) && n0 <= CAP) thr_closed = rmin;   // the zeros are ALL the non-zeros of p
+            }
+            // a support list, if wanted, must come out right: the zeros as candidates, or a count
+            // above cap (the row is marked, not listed); any other few-valued row goes the old way
+            closed = (one || two) && (list == nullptr || thr_closed < INFINITY || n_closed > cap);
+            if (__ballot(closed) != 0ull) {
+                stash[0] = thr_closed;
+                stash[64] = __int_as_float(s_closed);
+                stash[128] = __int_as_float(n_closed);
+                stash[192] = __int_as_float(__double2loint(S_closed));
+                stash[256] = __int_as_float(__double2hiint(S_closed));
+                fast = compact_above(floor_k);   // (own lane's words only: no synchronisation)
+            }
+        }
+    }
+    if (__builtin_expect(!fast, 0)) {
         // Narrow logit distributions.  Michelot starts from the threshold bound of the subset made
         // of one element per lane, its maximum -- (sum - 1) / count of them is below that subset's
         // threshold, which is below the row's -- and after every full-width step the candidates
@@ -1079,7 +1155,7 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
             // every row of the wave is at its fixed point, or one of them is there with more
             // elements above its threshold than a list holds (a wide support): full-width search
             all_fixed = __ballot(moving) == 0ull;
-            if (all_fixed || __ballot(!moving && cn > CAP) != 0ull) break;
+            if (all_fixed || __ballot(!closed && !moving && cn > CAP) != 0ull) break;
             if (moving) {
                 cnt_prev = cn;
                 tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
@@ -1089,19 +1165,25 @@ __device__ __forceinline__ bool sparsemax_row_group(float (&z)[E], WaveRed<G>& r
     bool listed = false;
     if (fast) {
         int m_robust = 0;
-        solve_core(c, red, CAP, s_final, S_final, &m_robust, tau);
+        solve_core(c, red, CAP, s_final, S_final, &m_robust, closed ? -1.0f : tau);
         // a list cut above the floor must be shown to hold everything the oracle could count
-        const bool complete = !(thr_used > floor_k) || lazy_list_is_complete(thr_used, tau_used, m_robust, K);
+        const bool complete = closed || !(thr_used > floor_k) || lazy_list_is_complete(thr_used, tau_used, m_robust, K);
         if (__ballot(!complete) != 0ull) fast = false;
     }
-    if (fast) {
-        if (list) {
-            const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-            n_listed = emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live, mark, vdelta);
-            listed = true;
+    if (!fast) solve_core(z, red, K, s_final, S_final, nullptr, tau, all_fixed);
+    const bool any_closed = __ballot(closed) != 0ull;
+    if (any_closed && closed) {
+        s_final = __float_as_int(stash[64]);
+        S_final = __hiloint2double(__float_as_int(stash[256]), __float_as_int(stash[192]));
+    }
+    if (fast && list) {
+        const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+        n_listed = emit_cols_from_candidates<Q, G>(c, cc, tau_c, gl, grp, list, cap, live, mark, vdelta);
+        if (any_closed && closed && !(stash[0] < INFINITY)) {   // nothing listed (but the stand-in): more than cap non-zeros
+            n_listed = __float_as_int(stash[128]);
+            if (live && gl == 0) list[0] = mark;
         }
-    } else {
-        solve_core(z, red, K, s_final, S_final, nullptr, tau, all_fixed);
+        listed = true;
     }
     const float c_s = (float)S_final - 1.0f;
     const float tau_f = c_s / (float)s_final;
@@ -1601,7 +1683,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
     constexpr bool CAND = (G == 64);
     constexpr bool GCAND = (G < 64) && (E >= 8);   // per-group candidate lists
     // per wave: kCandCap candidate values followed by kCandCap candidate columns
-    __shared__ float cand[(CAND || GCAND) ? kWavesPerBlock * 2 * kCandCap : 1];
+    // (+ 5 x 64 words per wave for the lane groups' closed forms, see sparsemax_row_group)
+    constexpr int kCandWords = 2 * kCandCap + (GCAND ? 5 * 64 : 0);
+    __shared__ float cand[(CAND || GCAND) ? kWavesPerBlock * kCandWords : 1];
     float z[E];
     load_row<E, VEC, FULL>(x + row * K, K, gl, G, z, -INFINITY);
     WaveRed<G> red;
@@ -1611,10 +1695,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, fwd_waves_per_eu(E, EXTRA)) vo
     bool listed;
     int n_listed = 0;   // #{p > 0} as counted by whoever wrote (or gave up on) the row's list
     if constexpr (GCAND)
-        listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * 2 * kCandCap, K, s, t,
+        listed = sparsemax_row_group<E, G, VEC>(z, red, cand + (threadIdx.x >> 6) * kCandWords, K, s, t,
                                                 n_listed, list, cap, live, mark, vdelta);
     else
-        listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * 2 * kCandCap : 0),
+        listed = sparsemax_row<E, 1, CAND, VEC>(z, red, cand + (CAND ? (threadIdx.x >> 6) * kCandWords : 0),
                                                 K, s, t, n_listed, list, cap, live, mark, vdelta);
     if constexpr (EXTRA) row_epilogue(z, red, nnz != nullptr, ent != nullptr, n, h);
     if (cols && !listed) n_listed = emit_support_cols<E, G, VEC>(z, gl, lane / G, list, cap, live, mark, vdelta);

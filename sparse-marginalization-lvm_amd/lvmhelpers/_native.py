@@ -108,8 +108,9 @@ def support_cols_cap(K):
 
 
 def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_cols=False,
-                  want_mask=False, want_vals=False):
+                  want_mask=False, want_vals=False, cols_cap=None):
     """x [R,K] f32 -> p [R,K], supp_size [R] i32, and the optional nnz/tau/entropy (or None).
+    cols_cap: slots per row of the lists (default support_cols_cap(K); the C ABI states the limits).
     want_cols=True appends the support lists [R, support_cols_cap(K)] i32 for sparsemax_bwd_cols;
     want_mask=True (with want_cols) appends the support-mask buffer as well (None when the shape
     has none: only 1024 < K <= 4096), which lets the backward skip p for rows with more non-zeros
@@ -128,7 +129,7 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
             _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
                                              _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
         return p, supp, nnz, tau, ent
-    cap = support_cols_cap(K)
+    cap = support_cols_cap(K) if cols_cap is None else int(cols_cap)
     cols = torch.empty((R, cap), dtype=torch.int32, device=x.device)
     mask = None
     if want_mask:

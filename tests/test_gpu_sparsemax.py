@@ -416,6 +416,75 @@ def test_few_valued_rows_and_exact_tie_groups(dev, oracle_mod, K):
     assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 2e-6 * np.abs(dy).max(axis=1, keepdims=True))
 
 
+@pytest.mark.parametrize("K", [64, 72, 100, 128, 129, 200, 256, 257, 300, 512])
+@pytest.mark.parametrize("cap", [8, 32, 64])
+def test_few_valued_rows_inside_mixed_waves_of_short_rows(dev, oracle_mod, K, cap):
+    """Rows of K <= 512 share a wave (2-8 rows side by side).  One- and two-valued rows are solved in
+    closed form there and kept out of the wave's candidate lists, so that their neighbours still get
+    the short search; every kind next to every other kind, in random order: p / supp / tau / nnz bit
+    for bit, the support lists exactly the non-zeros (or the overflow mark), the list backward and
+    the value lists."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(31 * K + cap)
+    f32 = np.float32
+    rows = []
+
+    def two_valued(a, v, base=0.0):
+        x = np.full(K, f32(base + v), f32)
+        x[rng.choice(K, a, replace=False)] = f32(base)
+        return x
+
+    for rep in range(6):
+        for v in (-1.0, -0.5, -0.999, -1.0 - 2 ** -20, -1.0 + 2 ** -20, -1e-3, -2.0, -1.0 / 3, -1.0 / 7):
+            for a in (1, 2, 5, cap, cap + 1, min(33, K - 1), K // 2, K - 1):
+                rows.append(two_valued(min(a, K - 1), v, base=float(rng.choice([0.0, 0.25, -3.0]))))
+        rows.append(np.full(K, f32(rng.choice([0.25, 0.0, -3.0])), f32))
+        x = two_valued(3, -1.0); x[rng.integers(K)] = -np.inf; rows.append(x)
+        x = np.full(K, f32(0.5), f32); x[rng.integers(K)] = -np.inf; rows.append(x)
+        x = two_valued(1, -1.0); x[K // 3] = f32(-1.5); rows.append(x)          # a third value
+        x = np.zeros(K, f32); x[1::2] = -0.5; x[3] = -0.75; rows.append(x)
+    n_few = len(rows)
+    rows += list(rng.standard_normal((n_few, K)).astype(f32))
+    rows += list((0.05 * rng.standard_normal((n_few // 2, K))).astype(f32))
+    rows += list((3.0 * rng.standard_normal((n_few // 2, K))).astype(f32))
+    x = np.stack(rows)[rng.permutation(len(rows))]
+    R = x.shape[0]
+    p_ref, s_ref, tau_ref, nnz_ref = oracle_mod.sparsemax_fwd(x)
+    xt = torch.from_numpy(x).to(dev)
+    for want_cols in (True, False):
+        out = _native.sparsemax_fwd(xt, want_nnz=True, want_tau=True, want_cols=want_cols, want_mask=want_cols,
+                                    **({"cols_cap": cap} if want_cols else {}))
+        p, supp, nnz, tau = out[0], out[1], out[2], out[3]
+        bad = np.flatnonzero(supp.cpu().numpy() != s_ref)
+        assert bad.size == 0, (bad[:8], supp.cpu().numpy()[bad[:8]], s_ref[bad[:8]])
+        assert np.array_equal(tau.cpu().numpy(), tau_ref)
+        assert np.array_equal(p.cpu().numpy(), p_ref)
+        assert np.array_equal(nnz.cpu().numpy(), nnz_ref)
+        if not want_cols:
+            continue
+        cols, mask = out[5], out[6]
+        c = cols.cpu().numpy()
+        assert c.shape[1] == cap
+        for r in range(R):
+            nz = np.flatnonzero(p_ref[r] > 0)
+            if nz.size > cap:
+                assert c[r, 0] in (-2, -3), (r, nz.size, c[r, :4])
+            else:
+                assert sorted(c[r, :nz.size].tolist()) == nz.tolist(), (r, nz.size, c[r, :8])
+                assert np.all(c[r, nz.size:] == -1)
+        dy = rng.standard_normal(x.shape).astype(np.float32)
+        dx_ref = oracle_mod.sparsemax_bwd(dy, p_ref, s_ref)
+        dxt = _native.sparsemax_bwd_cols(torch.from_numpy(dy).to(dev), cols, p, supp, mask)
+        assert np.all(np.abs(dxt.cpu().numpy() - dx_ref) <= 2e-6 * np.abs(dy).max(axis=1, keepdims=True))
+    # value lists next to the column lists (smlvm_sparsemax_fwd_lists)
+    out = _native.sparsemax_fwd(xt, want_cols=True, want_vals=True, cols_cap=cap)
+    c, v = out[5].cpu().numpy(), out[6].cpu().numpy()
+    for r in range(R):
+        n = int((p_ref[r] > 0).sum())
+        if n <= cap:
+            assert np.array_equal(v[r, :n], p_ref[r, c[r, :n]])
+
+
 def test_mask_mark_follows_the_nonzero_count(dev, oracle_mod):
     """A row is marked -3 (support mask) exactly when #{p > 0} exceeds the list capacity; the
     oracle's supp_size can be smaller than that count when a tie group straddles the threshold

@@ -4,6 +4,7 @@
  *   /tmp/sm_trace sample.bin 2>&1 | less
  *
  * sample.bin: int32 n, int32 budget, int32 max_iter, n floats (scores), 2n doubles (init scores);
+ * budget -1 = the binary sequence factor, n-1 floats (edge potentials) follow the init scores;
  * tools/sm_trace_dump.py writes one per sample that ends with a status other than CONVERGED.
  * Builds oracle/sparsemap_oracle.c with -DSM_TRACE: every pass prints what it did (ORACLE value - tau,
  * INSERT with the Schur complement s, REMOVE with alpha, FULLSTEP, POLISH / C7 residuals, C10).
@@ -25,6 +26,8 @@ int main(int argc, char** argv)
         fprintf(stderr, "bad sample file\n");
         return 2;
     }
+    float tr[SM_MAX_N];
+    if (budget < 0 && fread(tr, 4, n - 1, f) != (size_t)(n - 1)) { fprintf(stderr, "bad sample file\n"); return 2; }
     fclose(f);
     const int cap = n + 1, W = SM_WORDS(n), ld = cap + 1;
     uint32_t* ab = calloc((size_t)cap * W, 4);
@@ -32,7 +35,8 @@ int main(int argc, char** argv)
     double* p64 = calloc(cap, 8);
     double* inv = calloc((size_t)ld * ld, 8);
     int32_t alen, it, st;
-    oracle_sparsemap_fwd(x, init, budget, mi, 1, n, ab, p, p64, &alen, inv, &it, &st);
+    if (budget < 0) oracle_sparsemap_seq_fwd(x, tr, init, mi, 1, n, ab, p, p64, &alen, inv, &it, &st);
+    else oracle_sparsemap_fwd(x, init, budget, mi, 1, n, ab, p, p64, &alen, inv, &it, &st);
     fprintf(stderr, "END alen %d iters %d status %d\n", alen, it, st);
     return 0;
 }

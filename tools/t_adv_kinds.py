@@ -4,6 +4,9 @@ import sys
 import torch
 sys.path[:0] = ['.', 'sparse-marginalization-lvm_amd']
 from lvmhelpers import _native
+import os
+if os.environ.get('SMLVM_T_LIB'):   # A/B runs: another build of the library
+    _native.LIB_PATH = os.environ['SMLVM_T_LIB']
 
 dev = torch.device('cuda:0')
 
