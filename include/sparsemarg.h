@@ -31,7 +31,7 @@ extern "C" {
 
 /* Limits (smlvm_* returns SMLVM_ERR_UNSUPPORTED beyond them). */
 #define SMLVM_TOPK_MAX_BITS 512 /* lvmhelpers/binary_topk.h:13 CODE_MAX_SIZE */
-#define SMLVM_TOPK_MAX_K 64
+#define SMLVM_TOPK_MAX_K 1024 /* k <= 64: a lane group per sample; beyond: a workgroup per sample */
 #define SMLVM_SPARSEMAP_MAX_BITS 128
 
 int smlvm_abi_version(void);

@@ -2,7 +2,7 @@
 //
 // Replaces lvmhelpers/pbinary_topk.pyx:23-34 (batched_topk) and the per-row host DP of
 // lvmhelpers/binary_topk.h:57-129.  One group of G lanes (16 or 64) per sample, list slot j on lane
-// j.  Each DP step merges the sorted list `a` (bit i off) with `b = a + x_i` (bit i on) by merge
+// j (k <= 64; up to k = 1024 one workgroup per sample, see binary_topk_block_kernel).  Each DP step merges the sorted list `a` (bit i off) with `b = a + x_i` (bit i on) by merge
 // ranks instead of a serial two-pointer walk:
 //     rank(a_j) = j + #{l : b_l >  a_j}      (b is taken only if STRICTLY greater, binary_topk.h:72)
 //     rank(b_l) = l + #{j : a_j >= b_l}
@@ -131,6 +131,109 @@ __global__ __launch_bounds__(256) void binary_topk_kernel(const float* __restric
     }
 }
 
+// k > 64: the list no longer fits a wave.  One workgroup of T threads per sample, slot j on thread j,
+// everything that crossed lanes above goes through LDS.  With up to 1024 entries a linear count per
+// slot would be O(k) LDS reads per step; both lists are sorted (a by the DP's invariant, b = a + x_i
+// because fp32 addition of one x_i is monotone), so the two counts are the boundaries of monotone
+// predicates -- evaluated with the SAME fp32 expressions as the linear count -- and a binary search
+// finds each in <= 11 reads.  Same ranks, same tie rule, same bits as the wave kernel.
+template <int T, int W>
+__global__ __launch_bounds__(T) void binary_topk_block_kernel(const float* __restrict__ scores,
+                                                              float* __restrict__ configs,
+                                                              float* __restrict__ topscores,
+                                                              int64_t B, int n, int k)
+{
+    __shared__ float s_a[T];
+    __shared__ float s_score[T];
+    __shared__ int s_src[T];
+    __shared__ uint32_t s_cfg[W * T];   // word w of slot j at [w * T + j]
+    __shared__ float s_x[32 * W];
+
+    const int j = threadIdx.x;
+    const int64_t sample = blockIdx.x;   // grid == B
+    const float* x = scores + sample * n;
+    uint32_t cfg[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) cfg[w] = 0u;
+    for (int i = j; i < n; i += T) s_x[i] = x[i];
+    __syncthreads();
+    const float x0 = s_x[0];
+    const float c1 = 0.0f + x0;
+    const bool on_first = x0 >= 0.0f;
+    float a = -INFINITY;
+    if (j == 0) { a = on_first ? c1 : 0.0f; cfg[0] = on_first ? 1u : 0u; }
+    if (j == 1) { a = on_first ? 0.0f : c1; cfg[0] = on_first ? 0u : 1u; }
+    int L = 2;
+
+    for (int i = 1; i < n; ++i) {
+        const float xi = s_x[i];
+        const float b = a + xi;
+        s_a[j] = a;
+#pragma unroll
+        for (int w = 0; w < W; ++w) s_cfg[w * T + j] = cfg[w];
+        __syncthreads();
+        if (j < L) {
+            // cntA = #{t < L : a_t + x_i > a_j}, cntB = #{t < L : a_t >= b_j}: true ... true false ... false
+            int lo = 0, hi = L;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float bt = s_a[mid] + xi;
+                if (bt > a) lo = mid + 1; else hi = mid;
+            }
+            const int rA = j + lo;
+            lo = 0;
+            hi = L;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_a[mid] >= b) lo = mid + 1; else hi = mid;
+            }
+            const int rB = j + lo;
+            if (rA < k) { s_score[rA] = a; s_src[rA] = j; }
+            if (rB < k) { s_score[rB] = b; s_src[rB] = j | 0x10000; }
+        }
+        __syncthreads();
+        const int Ln = (2 * L < k) ? 2 * L : k;
+        float na = -INFINITY;
+        int src = j;
+        if (j < Ln) { na = s_score[j]; src = s_src[j]; }
+        const int sl = src & 0xffff;
+        const uint32_t bit = (src & 0x10000) ? (1u << (i & 31)) : 0u;
+        const int wi = i >> 5;
+#pragma unroll
+        for (int w = 0; w < W; ++w) cfg[w] = s_cfg[w * T + sl] | ((w == wi) ? bit : 0u);
+        __syncthreads();   // s_a / s_cfg / s_score are rewritten by the next step
+        a = na;
+        L = Ln;
+    }
+
+#pragma unroll
+    for (int w = 0; w < W; ++w) s_cfg[w * T + j] = cfg[w];
+    __syncthreads();
+    float* out = configs + sample * (int64_t)k * n;
+    const int total = k * n;
+    for (int idx = j; idx < total; idx += T) {
+        const int jj = idx / n, i = idx - jj * n;
+        out[idx] = (float)((s_cfg[(i >> 5) * T + jj] >> (i & 31)) & 1u);
+    }
+    if (topscores && j < k) topscores[sample * k + j] = a;
+}
+
+template <int T>
+static void launch_topk_block(const float* scores, float* configs, float* topscores, int64_t B,
+                              int n, int k, hipStream_t st)
+{
+    const int W = (n + 31) / 32;
+#define SMLVM_TOPK_GO(WW)                                                                        \
+    hipLaunchKernelGGL((binary_topk_block_kernel<T, WW>), dim3((unsigned)B), dim3(T), 0, st, scores, \
+                       configs, topscores, B, n, k)
+    if (W <= 1) SMLVM_TOPK_GO(1);
+    else if (W <= 2) SMLVM_TOPK_GO(2);
+    else if (W <= 4) SMLVM_TOPK_GO(4);
+    else if (W <= 8) SMLVM_TOPK_GO(8);
+    else SMLVM_TOPK_GO(16);
+#undef SMLVM_TOPK_GO
+}
+
 template <int G>
 static void launch_topk(const float* scores, float* configs, float* topscores, int64_t B, int n,
                         int k, hipStream_t st)
@@ -160,7 +263,10 @@ extern "C" int smlvm_binary_topk_batched(const float* scores, float* configs, fl
     if (n > SMLVM_TOPK_MAX_BITS || k > SMLVM_TOPK_MAX_K) return SMLVM_ERR_UNSUPPORTED;
     if (B == 0) return SMLVM_OK;
     if (!scores || !configs) return SMLVM_ERR_INVALID;
+    if (B > 0x7fffffffll) return SMLVM_ERR_UNSUPPORTED;
     if (k <= 16) launch_topk<16>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
-    else launch_topk<64>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
+    else if (k <= 64) launch_topk<64>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
+    else if (k <= 256) launch_topk_block<256>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
+    else launch_topk_block<1024>(scores, configs, topscores, B, n, k, (hipStream_t)stream);
     return check_launch();
 }

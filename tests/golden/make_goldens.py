@@ -5,6 +5,7 @@
 What is pinned by what:
   binary_topk.npz      inputs -> outputs of the COMPILED REFERENCE (oracle/_ref, built from the
                        reference's own lvmhelpers/binary_topk.h): a true reference golden.
+  binary_topk_wide.npz the same for k = 65 ... 1024 (configurations as packed bits).
   marg_*.npz           the reference's own Marginalizer / ExplicitWrapper classes
                        (lvmhelpers/marg.py, imported from /root/reference as text-unmodified
                        modules) run on CPU with toy encoder/decoder/loss.  With the softmax
@@ -127,6 +128,25 @@ def gold_binary_topk():
     np.savez_compressed(os.path.join(HERE, "binary_topk.npz"), n_cases=len(cases), **out)
 
 
+def gold_binary_topk_wide():
+    """k > 64 (round 3: the workgroup-per-sample kernel), same compiled reference, a file of its own so
+    that binary_topk.npz stays byte for byte what round 1 wrote."""
+    rng = np.random.default_rng(20261111)
+    out = {}
+    cases = [(6, 32, 65), (5, 7, 128), (4, 100, 100), (3, 40, 256), (3, 33, 257), (2, 512, 300),
+             (2, 64, 1000), (2, 200, 1024), (1, 10, 1024)]
+    for i, (B, n, k) in enumerate(cases):
+        x = rng.standard_normal((B, n)).astype(np.float32)
+        x[::3] = np.round(x[::3] * 2) / 2
+        if B > 2:
+            x[1] = 0.0
+        cfg, top = oracle.ref_binary_topk_batched(x, k)
+        # configurations as packed bits (k * n up to 204800 per sample)
+        out[f"scores_{i}"], out[f"k_{i}"], out[f"top_{i}"] = x, np.int32(k), top
+        out[f"configs_packed_{i}"] = np.packbits(cfg.astype(np.uint8), axis=-1)
+    np.savez_compressed(os.path.join(HERE, "binary_topk_wide.npz"), n_cases=len(cases), **out)
+
+
 def _run_marg(ref, normalizer, B, D, K, coeff, seed):
     torch.manual_seed(seed)
     enc, dec, x, labels = make_cat_problem(B, D, K, seed)
@@ -218,9 +238,15 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "needs /root/reference"
     oracle.build()
     only = sys.argv[1:]          # e.g. `make_goldens.py common_params`: regenerate just that fixture
+    if only == ["binary_topk_wide"]:   # needs the compiled header only, none of the Python modules
+        gold_binary_topk_wide()
+        print("goldens written to", HERE)
+        sys.exit(0)
     ref = _load_reference()
     if not only or "binary_topk" in only:
         gold_binary_topk()
+    if not only or "binary_topk_wide" in only:
+        gold_binary_topk_wide()
     if not only or "marg" in only:
         gold_marg(ref)
     if not only or "topk_marg" in only:

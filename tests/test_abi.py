@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(3), i32(9), null) == -1           # k > 2^n
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(8), i32(1), null) == -1           # k < 2
     assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(600), i32(4), null) == -2
-    assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(40), i32(65), null) == -2
+    assert lib.smlvm_binary_topk_batched(one, one, null, i64(2), i32(40), i32(1025), null) == -2
     assert lib.smlvm_sparsemap_fwd(one, null, i32(0), i32(10), i64(2), i32(129), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -2
     assert lib.smlvm_sparsemap_fwd(one, null, i32(-1), i32(10), i64(2), i32(16), one, one, one, null, null, null, null, ctypes.c_size_t(0), null) == -1
     # n > 64 needs the tier workspace

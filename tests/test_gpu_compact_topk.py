@@ -78,6 +78,27 @@ def test_binary_topk_matches_oracle(dev, oracle_mod, B, n, k):
     assert np.array_equal(cfg.cpu().numpy(), cfg_ref)
 
 
+@pytest.mark.parametrize("B,n,k", [(5, 32, 65), (9, 7, 128), (4, 100, 100), (3, 40, 256), (3, 33, 257),
+                                   (2, 512, 300), (2, 64, 1000), (2, 200, 1024), (1, 10, 1024), (70, 24, 90)])
+def test_binary_topk_beyond_one_wave(dev, oracle_mod, B, n, k):
+    """k > 64 (the reference takes any k, binary_topk.h:57-129): one workgroup per sample, merge
+    ranks by binary search instead of a linear count -- configurations and fp32 scores bit for bit
+    against the restatement and, where it was built, the reference's own header compiled in place."""
+    from lvmhelpers import _native
+    rng = np.random.default_rng(B + 17 * n + k)
+    scores = rng.standard_normal((B, n)).astype(np.float32)
+    scores[::3] = np.round(scores[::3] * 2) / 2          # ties
+    if B > 2:
+        scores[1] = 0.0                                   # all zero: every configuration ties
+    cfg_ref, top_ref = oracle_mod.binary_topk_batched(scores, k)
+    if oracle_mod.ref_lib() is not None:
+        cfg_r, top_r = oracle_mod.ref_binary_topk_batched(scores, k)
+        assert np.array_equal(cfg_r, cfg_ref) and np.array_equal(top_r, top_ref)
+    cfg, top = _native.binary_topk_batched(torch.from_numpy(scores).to(dev), k, want_scores=True)
+    assert np.array_equal(top.cpu().numpy(), top_ref)
+    assert np.array_equal(cfg.cpu().numpy(), cfg_ref)
+
+
 def test_binary_topk_rejects_undefined_cases(dev):
     from lvmhelpers import _native
     x = torch.zeros(2, 3, device=dev)
@@ -86,7 +107,7 @@ def test_binary_topk_rejects_undefined_cases(dev):
     with pytest.raises(_native.NativeError):
         _native.binary_topk_batched(x, 1)      # k < 2: UB in the reference
     with pytest.raises(_native.NativeError):
-        _native.binary_topk_batched(torch.zeros(2, 40, device=dev), 65)
+        _native.binary_topk_batched(torch.zeros(2, 40, device=dev), 1025)
 
 
 def test_pbinary_topk_host_api(dev, oracle_mod):
@@ -105,7 +126,7 @@ def test_pbinary_topk_host_api(dev, oracle_mod):
 def test_binary_topk_kernel_on_the_reference_golden_vectors(dev):
     """tests/golden/binary_topk.npz was produced by the reference's own binary_topk.h compiled in
     place (oracle/_ref, tests/golden/make_goldens.py); every case that the kernel's limits admit
-    (k <= 64, n <= 512) goes straight to smlvm_binary_topk_batched: configurations and fp32 scores
+    (k <= 1024, n <= 512) goes straight to smlvm_binary_topk_batched: configurations and fp32 scores
     bit for bit (lvmhelpers/binary_topk.h:57-129, pbinary_topk.pyx:23-34)."""
     import os
     from lvmhelpers import _native
@@ -117,6 +138,13 @@ def test_binary_topk_kernel_on_the_reference_golden_vectors(dev):
         cfg, top = _native.binary_topk_batched(torch.from_numpy(scores).to(dev), k, want_scores=True)
         assert np.array_equal(cfg.cpu().numpy().astype(np.uint8), d[f"configs_{i}"]), i
         assert np.array_equal(top.cpu().numpy(), d[f"top_{i}"]), i
+    w = np.load(os.path.join(os.path.dirname(__file__), "golden", "binary_topk_wide.npz"))   # k = 65 ... 1024
+    for i in range(int(w["n_cases"])):
+        scores, k = w[f"scores_{i}"], int(w[f"k_{i}"])
+        cfg, top = _native.binary_topk_batched(torch.from_numpy(scores).to(dev), k, want_scores=True)
+        want = np.unpackbits(w[f"configs_packed_{i}"], axis=-1)[..., :scores.shape[1]]
+        assert np.array_equal(cfg.cpu().numpy().astype(np.uint8), want), (i, k)
+        assert np.array_equal(top.cpu().numpy(), w[f"top_{i}"]), (i, k)
     # SURVEY.md 8(c)'s probe: binary_topk([0.5, -1, 2, 0.1], 5)
     cfg, top = _native.binary_topk_batched(torch.tensor([[0.5, -1.0, 2.0, 0.1]], device=dev), 5, want_scores=True)
     assert np.array_equal(cfg.cpu().numpy().astype(np.uint8), d["probe_configs"])

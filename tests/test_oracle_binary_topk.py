@@ -23,6 +23,18 @@ def test_golden_vectors_from_compiled_reference():
     assert cfg[0].tolist() == [[1, 0, 1, 1], [1, 0, 1, 0], [0, 0, 1, 1], [0, 0, 1, 0], [1, 1, 1, 1]]
 
 
+def test_golden_vectors_for_k_beyond_64():
+    """binary_topk_wide.npz: the compiled reference at k = 65 ... 1024 (configurations packed)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "binary_topk_wide.npz"))
+    assert int(g["n_cases"]) >= 9
+    for i in range(int(g["n_cases"])):
+        x, k = g[f"scores_{i}"], int(g[f"k_{i}"])
+        cfg, top = oracle.binary_topk_batched(x, k)
+        want = np.unpackbits(g[f"configs_packed_{i}"], axis=-1)[..., :x.shape[1]].astype(np.float32)
+        assert np.array_equal(cfg, want), i
+        assert np.array_equal(top, g[f"top_{i}"]), i
+
+
 @pytest.mark.skipif(oracle.ref_lib() is None, reason="oracle/_ref not built (needs /root/reference)")
 @pytest.mark.parametrize("B,n,k", [(50, 32, 10), (20, 128, 10), (30, 6, 64), (10, 512, 40), (40, 3, 8),
                                    (40, 1, 2), (25, 17, 2), (25, 64, 33)])
