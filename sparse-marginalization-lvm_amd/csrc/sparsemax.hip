@@ -57,6 +57,18 @@ struct WaveRed {
         S = group_reduce<G>(S, OpSum{});
         vn = group_reduce<G>(vn, OpMaxF{});
     }
+    __device__ __forceinline__ void sum2(double& a, double& b)
+    {
+        a = group_reduce<G>(a, OpSum{});
+        b = group_reduce<G>(b, OpSum{});
+    }
+    // two sums and a count (entmax15's closed form)
+    __device__ __forceinline__ void sums(double& a, double& b, int& c)
+    {
+        a = group_reduce<G>(a, OpSum{});
+        b = group_reduce<G>(b, OpSum{});
+        c = group_reduce<G>(c, OpSum{});
+    }
     // count, sum, smallest of a set and the largest element outside it
     __device__ __forceinline__ void first(int& m, double& S, float& lo, float& vn)
     {
@@ -186,6 +198,53 @@ struct BlockRed {
         t = bcast0(group_reduce<16>(pt, OpSum{}));
         S = bcast0(group_reduce<16>(pS, OpSum{}));
         vn = bcast0(group_reduce<16>(pv, OpMaxF{}));
+    }
+    __device__ __forceinline__ void sum2(double& a, double& b)   // one barrier for both
+    {
+        a = group_reduce<64>(a, OpSum{});
+        b = group_reduce<64>(b, OpSum{});
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) {
+            unsigned long long* rec = s + wave_index() * kSlots;
+            rec[0] = pack(a);
+            rec[1] = pack(b);
+        }
+        __syncthreads();
+        double pa = 0.0, pb = 0.0;
+        if (lane < NW) {
+            const int r = rec_of(lane);
+            pa = unpack<double>(s[r]);
+            pb = unpack<double>(s[r + 1]);
+        }
+        a = bcast0(group_reduce<16>(pa, OpSum{}));
+        b = bcast0(group_reduce<16>(pb, OpSum{}));
+    }
+    __device__ __forceinline__ void sums(double& a, double& b, int& c)   // one barrier for the three
+    {
+        a = group_reduce<64>(a, OpSum{});
+        b = group_reduce<64>(b, OpSum{});
+        c = group_reduce<64>(c, OpSum{});
+        unsigned long long* s = next_set();
+        const int lane = threadIdx.x & 63;
+        if (lane == 0) {
+            unsigned long long* rec = s + wave_index() * kSlots;
+            rec[0] = pack(a);
+            rec[1] = pack(b);
+            rec[2] = pack(c);
+        }
+        __syncthreads();
+        double pa = 0.0, pb = 0.0;
+        int pc = 0;
+        if (lane < NW) {
+            const int r = rec_of(lane);
+            pa = unpack<double>(s[r]);
+            pb = unpack<double>(s[r + 1]);
+            pc = unpack<int>(s[r + 2]);
+        }
+        a = bcast0(group_reduce<16>(pa, OpSum{}));
+        b = bcast0(group_reduce<16>(pb, OpSum{}));
+        c = bcast0(group_reduce<16>(pc, OpSum{}));
     }
     __device__ __forceinline__ void first(int& m, double& S, float& lo, float& vn)
     {
@@ -2520,8 +2579,63 @@ static void launch_bwd_stream(const BwdArgs& a)
 // parity (2e-6 on p), not bit parity: the package's fp32 cumsums are not reproduced.
 constexpr int kE15MaxNewton = 64;
 
-template <int E, class Red>
-__device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_out, float& tau_out)
+// One Newton step of f(tau) = sum max(v - tau, 0)^2 - 1 on the values v[] (fp32 partial sums per
+// lane, fp64 across lanes); returns the step, and in `lower` a LOWER bound of the size of
+// {v > tau}: (sum d)^2 <= count * sum d^2 (counting the set itself costs half a step more per
+// element, and rows that never get a list -- narrow logit distributions -- would pay it every step).
+template <int N, class Red>
+__device__ __forceinline__ float entmax15_newton_step(const float (&v)[N], float tau, Red& red, float& lower)
+{
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const float d = fmaxf(v[e] - tau, 0.0f);
+        s1 += d;
+        s2 = fmaf(d, d, s2);
+    }
+    double a = (double)s1, b = (double)s2;
+    red.sum2(a, b);
+    lower = (float)a * (float)a / (float)b;
+    return (float)((b - 1.0) / (2.0 * a));
+}
+
+// the package's closed form on the set {v > tau}: tau = mean - sqrt((1 - ss)/c), fp64
+template <int N, class Red>
+__device__ __forceinline__ float entmax15_closed_form(const float (&v)[N], float tau, Red& red)
+{
+    int c = 0;
+    double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const bool in = v[e] > tau;
+        const double w = in ? (double)v[e] : 0.0;
+        c += in ? 1 : 0;
+        S1 += w;
+        S2 += w * w;
+    }
+    red.sums(S1, S2, c);
+    if (c > 0) {
+        const double mean = S1 / (double)c, ss = S2 - (double)c * mean * mean;
+        const double delta = (1.0 - ss) / (double)c;
+        const float tc = (float)(mean - sqrt(delta > 0.0 ? delta : 0.0));
+        tau = tc > tau ? tc : tau;                   // (never below the Newton iterate)
+    }
+    return tau;
+}
+
+// NW = waves that hold the row (0: a lane group of one wave, no candidate lists).
+// cand: LDS, NW == 1: kCandCap floats private to the wave; NW > 1: NW*64 floats + NW ints.
+//
+// Candidates (round 3).  The Newton iterates rise monotonically and never pass the root, so every
+// set {z > tau_k} holds the support and the iteration from tau_k on only ever looks at that set.
+// Once it has at most kCandCap elements (after one or two full-width steps for N(0,1) logits) it
+// is compacted through LDS -- the same lists as sparsemax's threshold search -- and the remaining
+// ~10 steps and the closed form run on 4 values per lane instead of 64, without workgroup barriers
+// (every wave of a workgroup holds the same list).  Rows whose sets stay wide (narrow logit
+// distributions) iterate full width as before.
+template <int E, int NW, bool VEC, class Red>
+__device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_out, float& tau_out,
+                                             float* cand = nullptr)
 {
     float mx = z[0];
 #pragma unroll
@@ -2530,40 +2644,78 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
 #pragma unroll
     for (int e = 0; e < E; ++e) z[e] = (z[e] - mx) * 0.5f;   // padding stays -inf
     float tau = -1.0f;
-    for (int it = 0; it < kE15MaxNewton; ++it) {
-        float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const float d = fmaxf(z[e] - tau, 0.0f);
-            s1 += d;
-            s2 = fmaf(d, d, s2);
-        }
-        const double a = red.sum((double)s1), b = red.sum((double)s2);
-        const float step = (float)((b - 1.0) / (2.0 * a));
+    bool listed = false;
+    float c[kCandPerLane];
+    // attempt the compaction once the bound says the set may fit (for a tail of N(0,1) logits the
+    // set is about twice the bound); after a failure, when the bound has halved
+    float try_below = 0.4f * (float)kCandCap;
+    int it = 0;
+    for (; it < kE15MaxNewton; ++it) {
+        float cnt;
+        const float step = entmax15_newton_step(z, tau, red, cnt);
         const bool moving = step > 1e-7f;            // false for NaN rows too
         if (moving) tau += step;
         if (__ballot(moving) == 0ull) break;         // every row this wave holds has converged
-    }
-    // closed form on the remaining set (fp64 sums of z and z^2 over {z > tau})
-    int c = 0;
-    double S1 = 0.0, S2 = 0.0;
+        if constexpr (NW >= 1) {
+            // cnt bounds {z > tau_k} BEFORE the step; the set above the new tau is a subset
+            if (cnt <= try_below) {                  // wave- (NW == 1) / workgroup-uniform
+                const int lane = threadIdx.x & 63;
+                if constexpr (NW == 1) {
+                    const int n_c = compact_candidates<E, VEC>(z, tau, cand, kCandCap, nullptr, 0, 0);
+                    wave_lds_sync();
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool in = z[e] > tau;
-        const double v = in ? (double)z[e] : 0.0;
-        c += in ? 1 : 0;
-        S1 += v;
-        S2 += v * v;
+                    for (int q = 0; q < kCandPerLane; ++q) c[q] = (lane + 64 * q < n_c) ? cand[lane + 64 * q] : -INFINITY;
+                    wave_lds_sync();
+                    listed = n_c <= kCandCap;
+                } else {
+                    const int wave = wave_index();
+                    int* wcnt = reinterpret_cast<int*>(cand + NW * 64);
+                    const int n_w = compact_candidates<E, VEC>(z, tau, cand + wave * 64, 64, nullptr, 0, 0);
+                    if (lane == 0) wcnt[wave] = n_w;
+                    __syncthreads();
+                    int total = 0, worst = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int k = wcnt[w];
+                        total += k;
+                        worst = k > worst ? k : worst;
+                    }
+                    listed = worst <= 64 && total <= kCandCap;   // (a wave's list holds 64)
+                    if (listed) {
+#pragma unroll
+                        for (int q = 0; q < kCandPerLane; ++q) {
+                            const int idx = lane + 64 * q;
+                            float v = -INFINITY;
+                            int pre = 0;
+#pragma unroll
+                            for (int w = 0; w < NW; ++w) {
+                                const int k = wcnt[w];
+                                if (idx >= pre && idx < pre + k) v = cand[w * 64 + (idx - pre)];
+                                pre += k;
+                            }
+                            c[q] = v;
+                        }
+                    }
+                    __syncthreads();   // the lists are rewritten by the next attempt / the next row
+                }
+                if (listed) { ++it; break; }
+                try_below = 0.5f * cnt;
+            }
+        }
     }
-    c = red.sum(c);
-    S1 = red.sum(S1);
-    S2 = red.sum(S2);
-    if (c > 0) {
-        const double mean = S1 / (double)c, ss = S2 - (double)c * mean * mean;
-        const double delta = (1.0 - ss) / (double)c;
-        const float tc = (float)(mean - sqrt(delta > 0.0 ? delta : 0.0));
-        tau = tc > tau ? tc : tau;                   // (never below the Newton iterate)
+    if constexpr (NW >= 1) {
+        if (listed) {
+            WaveRed<64> wred;   // every wave solves the same small problem: no barriers
+            for (; it < kE15MaxNewton; ++it) {
+                float cnt;
+                const float step = entmax15_newton_step(c, tau, wred, cnt);
+                if (!(step > 1e-7f)) break;
+                tau += step;
+            }
+            tau = entmax15_closed_form(c, tau, wred);
+        }
     }
+    if (!listed) tau = entmax15_closed_form(z, tau, red);
     int n = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -2607,7 +2759,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 5 : 4) void entmax15
     WaveRed<G> red;
     int n;
     float t;
-    entmax15_row(z, red, n, t);
+    constexpr bool CAND = (G == 64);   // one row per wave: a candidate list per wave
+    __shared__ float cand[CAND ? kWavesPerBlock * kCandCap : 1];
+    entmax15_row<E, CAND ? 1 : 0, VEC>(z, red, n, t, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0));
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
         if (gl == 0) {
@@ -2623,6 +2777,7 @@ __global__ __launch_bounds__(64 * NW, 4) void entmax15_fwd_block_kernel(
     float* __restrict__ tau, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
+    __shared__ float cand[NW * 64 + NW];
     for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
         const int64_t row = rot8(row0, R);
         float z[E];
@@ -2630,7 +2785,7 @@ __global__ __launch_bounds__(64 * NW, 4) void entmax15_fwd_block_kernel(
         BlockRed<NW> red(lds);
         int n;
         float t;
-        entmax15_row(z, red, n, t);
+        entmax15_row<E, NW, VEC>(z, red, n, t, cand);
         store_row<E, VEC, FULL, true>(p + row * K, K, threadIdx.x, 64 * NW, z);
         if (threadIdx.x == 0) {
             if (nnz) nnz[row] = n;

@@ -38,12 +38,37 @@ def rows(rng, R, K):
     return x, (kind, sigma)
 
 
+def mixed_rows(rng, R, K):
+    """Rows of several kinds side by side in random order (rows of K <= 512 share a wave, and the
+    few-valued shortcuts of round 3 decide per row inside it), plus two-valued rows: a zeros over a
+    plateau at v."""
+    parts, tags = [], []
+    left = R
+    while left > 0:
+        r = int(rng.integers(1, left + 1))
+        if rng.random() < 0.35:
+            v = float(rng.choice([-1.0, -0.5, -0.999, -1.0 - 2 ** -20, -1.0 + 2 ** -20, -1e-3, -2.0, -1.0 / 3]))
+            base = float(rng.choice([0.0, 0.25, -3.0, 100.0]))
+            x = np.full((r, K), np.float32(base + v), np.float32)
+            for i in range(r):
+                a = int(rng.integers(1, max(2, min(K, int(rng.choice([2, 5, 40, K]))))))
+                x[i, rng.choice(K, min(a, K), replace=False)] = np.float32(base)
+            tag = ("two-valued", v)
+        else:
+            x, tag = rows(rng, r, K)
+        parts.append(x)
+        tags.append(tag)
+        left -= r
+    x = np.concatenate(parts)[rng.permutation(R)]
+    return x, ("mixed", tuple(tags[:4]))
+
+
 def sparsemax_trial(rng, trial):
     global bad
     K = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1100), rng.integers(1100, 4200),
                         rng.integers(4200, 70000), rng.choice([256, 1024, 4096, 8192, 65536, 131072])]))
     R = int(rng.integers(1, max(2, min(300, (1 << 21) // K))))
-    x, tag = rows(rng, R, K)
+    x, tag = mixed_rows(rng, R, K) if rng.random() < 0.5 else rows(rng, R, K)
     p_ref, s_ref, _, _ = oracle.sparsemax_fwd(x)
     xt = torch.from_numpy(x).to(dev)
     out = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True)
@@ -107,8 +132,8 @@ def sparsemap_trial(rng, trial):
 def topk_trial(rng, trial):
     global bad
     n = int(rng.integers(1, 200))
-    k = int(rng.integers(2, 65))
-    if n < 7:
+    k = int(rng.integers(2, 65)) if rng.random() < 0.7 else int(rng.integers(65, 1025))
+    if n < 11:
         k = min(k, 1 << n)
     if k < 2:
         return
