@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAT = {"fwd": "sparsemax_fwd", "bwd": "sparsemax_bwd", "count": "support_count_",
        "count_cols": "support_count_", "compact": "support_compact_",
        "compact_cols": "support_compact_", "offsets": "scan_", "wlr": "wlr_",
-       "sparsemap": "sparsemap_fwd_kernel"}
+       "sparsemap": "sparsemap_fwd_kernel", "fused": "support_compact_fused", "fwdadv": "sparsemax_fwd",
+       "efwd": "entmax15_fwd"}
 REPS = 3
 
 
@@ -51,7 +52,7 @@ def main():
         log = open(os.path.join(d, "time.log")).read()
         ms = float(re.search(r"([\d.]+) ms per call", log).group(1))
         R = int(re.search(r"R=(\d+)", log).group(1)) if "R=" in log else None
-        calls = REPS + (1 if what == "fwd" else 0)
+        calls = REPS + (1 if what == "fwd" else 0)   # (fwd's set-up launch is the same kernel)
         e = {"what": what, "ms_per_call": ms, "R": R}
         if m.group(2):
             e["K"], e["sigma"] = int(m.group(2)), float(m.group(3))

@@ -28,6 +28,19 @@ __global__ void k_gauss(float* x, size_t n, float sigma, unsigned long long seed
         x[i] = sigma * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
     }
 }
+// rows r % 4 == 0: all 0.25; 1: -1 with one 3.0; 2: -1 with one 0.0 (exact tie at the threshold); 3: left as is
+__global__ void k_adversarial(float* x, int64_t R, int K)
+{
+    const size_t n = (size_t)R * K;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t r = (int64_t)(i / K);
+        const int c = (int)(i - (size_t)r * K);
+        const int kind = (int)(r & 3);
+        if (kind == 0) x[i] = 0.25f;
+        else if (kind == 1) x[i] = (c == 7 % K) ? 3.0f : -1.0f;
+        else if (kind == 2) x[i] = (c == 0) ? 0.0f : -1.0f;
+    }
+}
 __global__ void k_unif64(double* x, size_t n, unsigned long long seed)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -108,7 +121,39 @@ int main(int argc, char** argv)
     const size_t mb = sym<mask_t>(h, "smlvm_sparsemax_support_mask_bytes")(R, K);
     if (mb) { CK(hipMalloc(&mask, mb)); CK(hipMemset(mask, 0, mb)); }
     hipLaunchKernelGGL(k_gauss, dim3(4096), dim3(256), 0, 0, x, n, sigma, 1ull);
+    if (!strcmp(what, "fwdadv"))   // SURVEY.md 8(d) S1 adversarial rows, a quarter each (bench.py's mix)
+        hipLaunchKernelGGL(k_adversarial, dim3(4096), dim3(256), 0, 0, x, R, K);
     CK(hipDeviceSynchronize());
+    if (!strcmp(what, "fwdadv")) {
+        timed([&] { return fwdc(x, p, supp, nullptr, nullptr, nullptr, cols, cap, mask, R, K, nullptr); });
+        return 0;
+    }
+    if (!strcmp(what, "efwd")) {   // entmax15 forward
+        typedef int (*e15_t)(const float*, float*, int32_t*, float*, int64_t, int32_t, void*);
+        auto f = sym<e15_t>(h, "smlvm_entmax15_fwd");
+        timed([&] { return f(x, p, nullptr, nullptr, R, K, nullptr); });
+        return 0;
+    }
+    if (!strcmp(what, "fused")) {  // single-pass compaction from the forward's column + value lists
+        typedef int (*fwdl_t)(const float*, float*, int32_t*, int32_t*, float*, float*, int32_t*, float*, int, uint32_t*, int64_t, int, void*);
+        typedef int (*fused_t)(const float*, const int32_t*, const float*, int32_t, int64_t*, int32_t*, int32_t*, float*, int64_t,
+                               int64_t, int32_t, void*, size_t, void*);
+        auto fl = sym<fwdl_t>(h, "smlvm_sparsemax_fwd_lists");
+        auto ff = sym<fused_t>(h, "smlvm_support_compact_fused");
+        auto wsz = sym<szr_t>(h, "smlvm_support_compact_fused_workspace_bytes");
+        float* vals_l; CK(hipMalloc(&vals_l, (size_t)R * cap * 4));
+        if (fl(x, p, supp, nnz, nullptr, nullptr, cols, vals_l, cap, mask, R, K, nullptr)) { printf("setup fwd_lists failed\n"); return 1; }
+        const int64_t n_cap = R * (int64_t)cap;
+        int64_t* off; void* ws; const size_t wb = wsz(R);
+        int32_t *rows, *cc; float* vals;
+        CK(hipMalloc(&off, (R + 1) * 8)); CK(hipMalloc(&ws, wb));
+        CK(hipMalloc(&rows, n_cap * 4)); CK(hipMalloc(&cc, n_cap * 4)); CK(hipMalloc(&vals, n_cap * 4));
+        CK(hipDeviceSynchronize());
+        timed([&] { return ff(p, cols, vals_l, cap, off, rows, cc, vals, n_cap, R, K, ws, wb, nullptr); });
+        int64_t N; CK(hipMemcpy(&N, off + R, 8, hipMemcpyDeviceToHost));
+        printf("N = %lld\n", (long long)N);
+        return 0;
+    }
     // one forward prepares p, supp, nnz and the support lists for everything else
     // (for the forward target the same instantiation as the timed calls: the variant with optional
     // outputs spills to scratch at K >= 4096, which would be averaged into the forward's traffic)
