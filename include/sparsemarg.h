@@ -178,6 +178,21 @@ int smlvm_support_compact_fused(const float* p, const int32_t* support_cols, con
                                 int32_t cap, int64_t* row_offsets, int32_t* rows, int32_t* cols,
                                 float* vals, int64_t n_cap, int64_t R, int32_t K, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* Entropy of the compacted distribution and the gather it is taken over.  Replaces
+ * lvmhelpers/structmarg.py:51-54 and :200 (`-(distr @ torch.log(distr)) / batch_size`, seven
+ * elementwise launches forward and six backward) and the advanced indexing `p[rows, cols]` of
+ * structmarg.py:123-126,189-190 whose backward sorts its indices:
+ *   entropy_fwd: total[0] = -inv_b * sum_{vals[j] > 0} vals[j] log vals[j] (fp64 two-stage sum, fixed
+ *                order; workspace: smlvm_weighted_loss_reduce_workspace_bytes(N) bytes);
+ *   entropy_bwd: dvals[j] = -(log vals[j] + 1) * inv_b * gtotal[0] for vals[j] > 0, else 0;
+ *   scatter:     out [R, K] = 0 except out[r, cols[j]] = g[j] for j in [row_offsets[r],
+ *                row_offsets[r+1]) -- the backward of vals = p[rows, cols] (positions are distinct). */
+int smlvm_support_entropy_fwd(const float* vals, int64_t N, float inv_b, float* total, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int smlvm_support_entropy_bwd(const float* vals, const float* gtotal, float inv_b, float* dvals,
+                              int64_t N, void* stream);
+int smlvm_support_scatter(const float* g, const int64_t* row_offsets, const int32_t* cols, float* out,
+                          int64_t R, int32_t K, void* stream);
 size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N);
 int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps, const int64_t* row_offsets,
                                    float* row_out, float* total, float inv_b, int64_t R, int64_t N,

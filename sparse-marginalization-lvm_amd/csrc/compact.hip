@@ -616,13 +616,29 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
             }
         }
     }
+    // No lists at all and short rows (the SparseMAP distributions: [B, n + 1] with n <= 63, or a
+    // [B, k] top-k distribution): a lane per row.  A wave per row, one row after the other, is 128
+    // dependent round trips for a tile of 64 rows -- 47 us for the 64 x 33 batch of the 32-bit VAE,
+    // which the host then waits for (it reads the offsets back).
+    const bool lane_rows = lists == nullptr && K <= 64;
+    if (lane_rows) {
+        const int64_t r = row_base + lane;
+        int c = 0;
+        if (r < R) {
+            const float* pr = p + r * K;
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) c += pr[k] > 0.0f ? 1 : 0;
+        }
+        cnt[wave * 64 + lane] = c;
+    } else {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
-            const int g = __builtin_ctzll(todo) / G;
-            const int64_t r = row_base + s * RW + g;
-            const int c = count_row_scan<VEC>(p + r * K, K, lane);
-            if (lane == 0) cnt[wave * 64 + s * RW + g] = c;
+        for (int s = 0; s < S; ++s) {
+            for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
+                const int g = __builtin_ctzll(todo) / G;
+                const int64_t r = row_base + s * RW + g;
+                const int c = count_row_scan<VEC>(p + r * K, K, lane);
+                if (lane == 0) cnt[wave * 64 + s * RW + g] = c;
+            }
         }
     }
     __syncthreads();
@@ -749,10 +765,30 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
                 }
             }
         }
+        if (lane_rows) continue;
         for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
             const int g = __builtin_ctzll(todo) / G;
             const int64_t r = row_base + s * RW + g;
             compact_row_scan_lim<VEC>(p + r * K, K, lane, r, offs[wave * 64 + s * RW + g], n_cap, rows, cols, vals);
+        }
+    }
+    if (lane_rows) {
+        const int64_t r = row_base + lane;
+        if (r < R) {
+            int64_t pos = offs[wave * 64 + lane];
+            const float* pr = p + r * K;
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) {
+                const float v = pr[k];
+                if (v > 0.0f) {
+                    if (pos < n_cap) {
+                        if (rows) rows[pos] = (int32_t)r;
+                        if (cols) cols[pos] = k;
+                        if (vals) vals[pos] = v;
+                    }
+                    ++pos;
+                }
+            }
         }
     }
 }
@@ -789,6 +825,60 @@ __global__ __launch_bounds__(256) void wlr_partial_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// -sum_{v > 0} v log v over the compacted (or dense) distribution, same fixed two-stage shape
+// (structmarg.py:51-54, 200: `-(distr @ torch.log(distr))`, entries that are not positive skipped)
+__global__ __launch_bounds__(256) void plogp_partial_kernel(const float* __restrict__ vals,
+                                                            double* __restrict__ partials, int64_t N,
+                                                            int64_t per_block)
+{
+    __shared__ double lds[4];
+    const int64_t lo = (int64_t)blockIdx.x * per_block;
+    const int64_t hi = lo + per_block < N ? lo + per_block : N;
+    double acc = 0.0;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += 256) {
+        const float v = vals[j];
+        if (v > 0.0f) acc += (double)(v * logf(v));
+    }
+    acc = group_reduce<64>(acc, OpSum{});
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// d/dv of -scale * sum v log v, times the incoming gradient: -(log v + 1) scale g for v > 0, else 0
+__global__ __launch_bounds__(256) void plogp_bwd_kernel(const float* __restrict__ vals,
+                                                        const float* __restrict__ gout, float scale,
+                                                        float* __restrict__ dvals, int64_t N)
+{
+    const float g = gout[0] * scale;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256) {
+        const float v = vals[j];
+        dvals[j] = v > 0.0f ? -(logf(v) + 1.0f) * g : 0.0f;
+    }
+}
+
+// out[r, :] = 0 except out[r, cols[j]] = g[j] for the row's entries j in [row_offsets[r],
+// row_offsets[r+1]): the backward of gathering the compacted values out of a dense [R, K] tensor
+// (positions are distinct, so nothing has to be sorted or accumulated).  One wave per row.
+__global__ __launch_bounds__(256) void support_scatter_kernel(const float* __restrict__ g,
+                                                              const int64_t* __restrict__ row_offsets,
+                                                              const int32_t* __restrict__ cols,
+                                                              float* __restrict__ out, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;   // whole wave
+    float* o = out + r * K;
+    for (int k = lane; k < K; k += 64) o[k] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the zeros before the entries, same wave
+    __builtin_amdgcn_wave_barrier();
+    const int64_t lo = row_offsets[r], hi = row_offsets[r + 1];
+    for (int64_t j = lo + lane; j < hi; j += 64) {
+        const int c = cols[j];
+        if (c >= 0 && c < K) o[c] = g[j];
+    }
 }
 
 __global__ __launch_bounds__(64) void wlr_final_kernel(const double* __restrict__ partials,
@@ -1086,6 +1176,47 @@ extern "C" int smlvm_weighted_loss_reduce_bwd(const float* vals, const float* co
     int64_t blocks = (N + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wlr_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vals, comps, gtotal, inv_b, dvals, dcomps, N);
+    return check_launch();
+}
+
+extern "C" int smlvm_support_entropy_fwd(const float* vals, int64_t N, float inv_b, float* total,
+                                         void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (N < 0 || !total) return SMLVM_ERR_INVALID;
+    if (N > 0 && !vals) return SMLVM_ERR_INVALID;
+    if (!workspace || workspace_bytes < smlvm_weighted_loss_reduce_workspace_bytes(N)) return SMLVM_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    int64_t per_block = (N + kRedBlocks - 1) / kRedBlocks;
+    if (per_block < 256) per_block = 256;
+    const int nparts = (int)((N + per_block - 1) / per_block);
+    if (nparts > 0)
+        hipLaunchKernelGGL(plogp_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, partials, N, per_block);
+    hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, -inv_b, total);
+    return check_launch();
+}
+
+extern "C" int smlvm_support_entropy_bwd(const float* vals, const float* gtotal, float inv_b,
+                                         float* dvals, int64_t N, void* stream)
+{
+    if (N < 0) return SMLVM_ERR_INVALID;
+    if (N == 0) return SMLVM_OK;
+    if (!vals || !gtotal || !dvals) return SMLVM_ERR_INVALID;
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(plogp_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vals, gtotal, inv_b, dvals, N);
+    return check_launch();
+}
+
+extern "C" int smlvm_support_scatter(const float* g, const int64_t* row_offsets, const int32_t* cols,
+                                     float* out, int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!row_offsets || !out) return SMLVM_ERR_INVALID;   // (g / cols may be NULL only if N == 0: not checkable here)
+    if (!g || !cols) return SMLVM_ERR_INVALID;
+    if ((R + 3) / 4 > 0x7fffffffll) return SMLVM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(support_scatter_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, row_offsets, cols, out, R, K);
     return check_launch();
 }
 

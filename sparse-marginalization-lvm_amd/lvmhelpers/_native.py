@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "smlvm_sparsemax_fwd_lists", "smlvm_support_compact_fused_workspace_bytes", "smlvm_support_compact_fused",
     "smlvm_weighted_loss_reduce_workspace_bytes",
     "smlvm_weighted_loss_reduce_fwd", "smlvm_weighted_loss_reduce_bwd",
+    "smlvm_support_entropy_fwd", "smlvm_support_entropy_bwd", "smlvm_support_scatter",
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
     "smlvm_sparsemap_bwd", "smlvm_sparsemap_seq_fwd", "smlvm_sparsemap_seq_bwd",
     "smlvm_unpack_configs",
@@ -407,6 +408,46 @@ def weighted_loss_reduce_bwd(vals, comps, gtotal, inv_b, want_dvals=True, want_d
     return dvals, dcomps
 
 
+def support_entropy_fwd(vals, inv_b=1.0):
+    """-inv_b * sum_{v > 0} v log v over all entries of vals (any shape) -> [1] f32."""
+    vals = _need_gpu(vals, torch.float32, "vals")
+    N = vals.numel()
+    total = torch.empty(1, dtype=torch.float32, device=vals.device)
+    nbytes = lib().smlvm_weighted_loss_reduce_workspace_bytes(N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=vals.device)
+    with torch.cuda.device(vals.device):
+        _check(lib().smlvm_support_entropy_fwd(_p(vals), _i64(N), _f32(inv_b), _p(total), _p(ws),
+                                               ctypes.c_size_t(nbytes), _stream()), "smlvm_support_entropy_fwd")
+    return total
+
+
+def support_entropy_bwd(vals, gtotal, inv_b=1.0):
+    vals = _need_gpu(vals, torch.float32, "vals")
+    gtotal = _need_gpu(gtotal.reshape(1), torch.float32, "gtotal")
+    dvals = torch.empty_like(vals)
+    with torch.cuda.device(vals.device):
+        _check(lib().smlvm_support_entropy_bwd(_p(vals), _p(gtotal), _f32(inv_b), _p(dvals),
+                                               _i64(vals.numel()), _stream()), "smlvm_support_entropy_bwd")
+    return dvals
+
+
+def support_scatter(g, row_offsets, cols, R, K):
+    """Dense [R, K] with g[j] at (row of j, cols[j]) and zeros elsewhere (j in row-major compaction
+    order, rows given by row_offsets [R+1])."""
+    g = _need_gpu(g, torch.float32, "g")
+    row_offsets = _need_gpu(row_offsets, torch.int64, "row_offsets")
+    cols = _need_gpu(cols, torch.int32, "cols")
+    if row_offsets.shape[0] != R + 1 or cols.shape[0] != g.shape[0]:
+        raise ValueError("support_scatter: row_offsets must be [R+1], cols and g of one length")
+    out = torch.empty((R, K), dtype=torch.float32, device=g.device)
+    if g.shape[0] == 0:
+        return out.zero_()
+    with torch.cuda.device(g.device):
+        _check(lib().smlvm_support_scatter(_p(g), _p(row_offsets), _p(cols), _p(out), _i64(R), _i32(K),
+                                           _stream()), "smlvm_support_scatter")
+    return out
+
+
 # ----------------------------------------------------------------------------------- top-k
 def binary_topk_batched(scores, k, want_scores=False):
     scores = _need_gpu(scores, torch.float32, "scores")
@@ -560,8 +601,9 @@ def lowrank_ce_bwd(x, w, b, y, lse, gloss, want_dx=True, want_dw=True):
     y, kind = _labels(y, N, F)
     dev = x.device
     dx = torch.empty_like(x) if want_dx else None
-    dw = torch.zeros_like(w) if want_dw else None
-    db = torch.zeros_like(b) if want_dw else None
+    # (the reduction kernel writes every entry; only an empty batch leaves them untouched)
+    dw = (torch.empty_like(w) if N > 0 else torch.zeros_like(w)) if want_dw else None
+    db = (torch.empty_like(b) if N > 0 else torch.zeros_like(b)) if want_dw else None
     nbytes = lib().smlvm_lowrank_ce_bwd_workspace_bytes(N, F, C, R) if want_dw else 0
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):

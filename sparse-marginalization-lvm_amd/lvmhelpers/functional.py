@@ -111,6 +111,52 @@ class _WeightedLossReduce(torch.autograd.Function):
         return dv, dc, None
 
 
+class _SupportEntropy(torch.autograd.Function):
+    """-inv_b * sum_{p > 0} p log p in two launches forward and one backward (structmarg.py:51-54,
+    200: seven elementwise launches forward, six backward, at batch 64 all of them launch latency)."""
+
+    @staticmethod
+    def forward(ctx, p, inv_b):
+        p = p.contiguous()
+        ctx.save_for_backward(p)
+        ctx.inv_b = inv_b
+        return _native.support_entropy_fwd(p, inv_b).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        return _native.support_entropy_bwd(p, g.to(torch.float32), ctx.inv_b), None
+
+
+def support_entropy(p, inv_b=1.0):
+    """-(p[p > 0] @ log p[p > 0]) * inv_b as a 0-d tensor (no clamping: structmarg.py:51-54, 200)."""
+    return _SupportEntropy.apply(p, float(inv_b))
+
+
+class _GatherSupport(torch.autograd.Function):
+    """vals = p[rows, cols] for the compaction's (rows, cols), whose values the compaction kernel has
+    already written: the forward launches nothing, the backward is one scatter of distinct
+    positions (torch's index backward zero-fills, sorts the indices and accumulates: 7 launches)."""
+
+    @staticmethod
+    def forward(ctx, p, row_offsets, cols, vals):
+        ctx.save_for_backward(row_offsets, cols)
+        ctx.shape = tuple(p.shape)
+        return vals.view_as(vals)
+
+    @staticmethod
+    def backward(ctx, g):
+        row_offsets, cols = ctx.saved_tensors
+        R, K = ctx.shape
+        return _native.support_scatter(g.contiguous(), row_offsets, cols, R, K), None, None, None
+
+
+def gather_support(p, row_offsets, cols, vals):
+    """The compacted probabilities `vals` (== p[rows, cols], row-major) as a differentiable function
+    of p [R, K]."""
+    return _GatherSupport.apply(p, row_offsets, cols, vals)
+
+
 class _SparseMAP(torch.autograd.Function):
     """Batched bit-vector SparseMAP (sparsemap.py:12-44 for every sample of the batch at once)."""
 

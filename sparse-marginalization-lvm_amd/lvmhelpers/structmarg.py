@@ -20,10 +20,9 @@ def entropy(p):
     return F_.entropy(p)
 
 
-def _support_entropy(p):
-    """-sum_{p>0} p log p, no clamping (structmarg.py:51-54, 200)."""
-    safe = torch.where(p > 0, p, torch.ones_like(p))
-    return -(p * safe.log()).sum()
+def _support_entropy(p, inv_b=1.0):
+    """-inv_b sum_{p>0} p log p, no clamping (structmarg.py:51-54, 200), one fused reduction."""
+    return F_.support_entropy(p, inv_b)
 
 
 class TopKSparsemaxWrapper(nn.Module):
@@ -43,8 +42,7 @@ class TopKSparsemaxWrapper(nn.Module):
         bit_vector_z, _ = _native.binary_topk_batched(scores.detach(), self.k)
         topk_scores = torch.einsum("bkj,bj->bk", bit_vector_z, scores)
         distr = F_.sparsemax(topk_scores, dim=-1)
-        entropy_distr = _support_entropy(distr)
-        return bit_vector_z, distr, entropy_distr / batch_size
+        return bit_vector_z, distr, _support_entropy(distr, 1.0 / batch_size)
 
 
 class TopKSparsemaxMarg(torch.nn.Module):
@@ -75,13 +73,14 @@ class TopKSparsemaxMarg(torch.nn.Module):
         entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
 
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
-        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False,
-                                                      support_cols=F_.support_cols_of(encoder_probs))
+        off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
+                                                        support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         encoder_input_sel = encoder_input[rows_l]
         decoder_input_sel = decoder_input[rows_l]
         labels_sel = labels[rows_l]
-        probs_sel = encoder_probs[rows_l, cols_l]
+        # the compaction has the selected probabilities already; their gradient goes back with one scatter
+        probs_sel = F_.gather_support(encoder_probs, off, cols, vals)
         bit_vector_z_flat = bit_vector_z[rows_l, cols_l]
 
         decoder_output = self.decoder(bit_vector_z_flat, decoder_input)
@@ -151,24 +150,24 @@ class SparseMAPWrapper(nn.Module):
         # support[b] times: the compaction is in row-major order) follow from them on the host,
         # while the compaction itself runs on the device.
         # (count + offsets + compaction are one launch; N and the offsets come back in one copy)
-        fused = _native.support_compact_fused(p.detach(), want_vals=False, host_offsets=True)
+        fused = _native.support_compact_fused(p.detach(), want_vals=True, host_offsets=True)
         if fused is None:   # a batch too large for the single-pass bound: separate launches
             off = _native.support_row_offsets(p.detach())
             off_h = off.cpu().numpy()
-            _, rows, cols, _ = _native.support_compact(p.detach(), want_vals=False, row_offsets=off,
-                                                       total=int(off_h[-1]), fused=False)
+            _, rows, cols, vals = _native.support_compact(p.detach(), want_vals=True, row_offsets=off,
+                                                          total=int(off_h[-1]), fused=False)
         else:
-            _, rows, cols, _, off_h = fused
+            off, rows, cols, vals, off_h = fused
         counts = np.diff(off_h)
         support = counts.tolist()
         assert min(support) > 0
         idxs = np.repeat(np.arange(batch_size), counts).tolist()
         rows_l = rows.long()
         sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
-        distr = p[rows_l, cols.long()]
-        entropy_distr = _support_entropy(distr)
+        # the compaction wrote the selected probabilities; their gradient goes back with one scatter
+        distr = F_.gather_support(p, off, cols, vals)
         self._idx_tensor = rows_l
-        return sample, distr, entropy_distr / batch_size, idxs, support
+        return sample, distr, _support_entropy(distr, 1.0 / batch_size), idxs, support
 
 
 class SparseMAPMarg(torch.nn.Module):

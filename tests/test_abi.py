@@ -106,6 +106,12 @@ def test_argument_validation_without_gpu(lib):
     assert fused(one, null, one, i32(0), one, null, null, null, i64(0), i64(3), i32(4), one, sz(1 << 20), null) == -1    # vals without cols
     assert fused(one, null, null, i32(0), null, null, null, null, i64(0), i64(3), i32(4), one, sz(1 << 20), null) == -1  # no offsets
     assert fused(one, null, null, i32(0), one, null, null, null, i64(0), i64(3), i32(4), null, sz(0), null) == -4        # no workspace
+    assert lib.smlvm_support_entropy_fwd(one, i64(-1), ctypes.c_float(1.0), one, one, sz(1 << 20), null) == -1
+    assert lib.smlvm_support_entropy_fwd(one, i64(5), ctypes.c_float(1.0), one, null, sz(0), null) == -4
+    assert lib.smlvm_support_entropy_bwd(one, null, ctypes.c_float(1.0), one, i64(5), null) == -1
+    assert lib.smlvm_support_entropy_bwd(null, null, ctypes.c_float(1.0), null, i64(0), null) == 0
+    assert lib.smlvm_support_scatter(one, null, one, one, i64(3), i32(4), null) == -1
+    assert lib.smlvm_support_scatter(null, null, null, null, i64(0), i32(4), null) == 0
     assert lib.smlvm_sparsemax_fwd_lists(one, one, one, null, null, null, one, one, i32(32), null, i64(3), i32(8192), null) == -2
     assert lib.smlvm_sparsemax_fwd_lists(one, one, one, null, null, null, null, one, i32(32), null, i64(3), i32(64), null) == -1
     assert lib.smlvm_support_count_cols(one, one, i32(0), one, i64(3), i32(4), null) == -1

@@ -217,7 +217,8 @@ def test_list_fed_kernels_on_handmade_lists(dev, oracle_mod, R, K, cap):
 @pytest.mark.parametrize("R,K,sigma", [(64, 10, 1.0), (64, 256, 1.0), (300, 1000, 1.0), (64, 4096, 1.0),
                                        (64, 4096, 0.05), (1000, 256, 0.05), (5000, 256, 1.0), (20, 8192, 1.0),
                                        (257, 4096, 0.2), (1, 64, 1.0), (255, 128, 1.0), (256, 128, 1.0),
-                                       (70000, 64, 1.0)])
+                                       (70000, 64, 1.0), (64, 33, 1.0), (513, 63, 0.3), (1000, 1, 1.0),
+                                       (3, 2, 1.0), (4100, 17, 0.05)])
 def test_fused_single_pass_compaction(dev, R, K, sigma):
     """smlvm_support_compact_fused (count + look-back scan + compaction in one launch) against the
     separate launches: same offsets / rows / cols / vals bit for bit -- fed with nothing (scan of
@@ -330,3 +331,58 @@ def test_support_tag_goes_stale_when_p_is_modified(dev):
     _, rows2, cols2, _ = _native.support_compact(p, support_cols=F_.support_cols_of(p))
     assert int(cols2.max()) >= 32 and int(cols2.min()) >= 32
     assert F_.support_cols_of(p.clone()) is None and F_.support_cols_of(p.detach()) is None
+
+
+@pytest.mark.parametrize("shape", [(1,), (7,), (640,), (64, 10), (100000,), (3000001,)])
+def test_support_entropy_fused_reduction(dev, shape):
+    """-(p @ log p)/B over the positive entries (structmarg.py:51-54, 200) as two launches forward
+    and one backward: value and gradient against the reference's own torch expression in fp64."""
+    from lvmhelpers import functional as F_
+    g = torch.Generator(device=dev).manual_seed(sum(shape))
+    p = torch.rand(shape, device=dev, generator=g)
+    p = torch.where(torch.rand(shape, device=dev, generator=g) < 0.3, torch.zeros_like(p), p)   # exact zeros
+    p = (p / p.sum()).requires_grad_(True)
+    inv_b = 1.0 / 64
+    h = F_.support_entropy(p, inv_b)
+    assert h.dim() == 0
+    (3.0 * h).backward()
+    p64 = p.detach().double().requires_grad_(True)
+    pos = p64[p64 > 0]
+    ref = -(pos @ torch.log(pos)) * inv_b
+    (3.0 * ref).backward()
+    assert abs(h.item() - ref.item()) <= 1e-6 * max(1.0, abs(ref.item()))
+    gref = p64.grad
+    assert torch.all(p.grad[p.detach() <= 0] == 0)
+    assert torch.allclose(p.grad.double(), torch.where(p64 > 0, gref, torch.zeros_like(gref)), rtol=1e-5, atol=1e-7)
+
+
+def test_support_entropy_of_nothing_is_zero(dev):
+    from lvmhelpers import functional as F_
+    assert F_.support_entropy(torch.zeros(5, device=dev)).item() == 0.0
+    assert F_.support_entropy(torch.zeros(0, device=dev)).item() == 0.0
+
+
+@pytest.mark.parametrize("R,K", [(64, 33), (1, 1), (300, 10), (1000, 256), (7, 4096)])
+def test_gather_support_is_the_indexing_it_replaces(dev, R, K):
+    """vals = p[rows, cols] without a launch (the compaction wrote them) and with ONE scatter as
+    its backward: same values, same gradient as torch's advanced indexing (structmarg.py:123-126,
+    189-190), rows without entries included."""
+    from lvmhelpers import _native, functional as F_
+    g = torch.Generator(device=dev).manual_seed(R * K)
+    p = torch.rand(R, K, device=dev, generator=g)
+    p = torch.where(torch.rand(R, K, device=dev, generator=g) < 0.8, torch.zeros_like(p), p)
+    if R > 2:
+        p[1] = 0.0                                     # an empty row
+    off, rows, cols, vals = _native.support_compact(p)
+    pa = p.clone().requires_grad_(True)
+    pb = p.clone().requires_grad_(True)
+    va = F_.gather_support(pa, off, cols, vals)
+    vb = pb[rows.long(), cols.long()]
+    assert torch.equal(va, vb)
+    w = torch.randn(va.shape[0], device=dev, generator=g)
+    (va * w).sum().backward()
+    (vb * w).sum().backward()
+    assert torch.equal(pa.grad, pb.grad)
+    dense = _native.support_scatter(w, off, cols, R, K)
+    assert torch.equal(dense, pb.grad)
+
