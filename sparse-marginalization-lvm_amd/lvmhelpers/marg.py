@@ -106,8 +106,8 @@ class Marginalizer(torch.nn.Module):
     def _forward_compact(self, encoder_input, decoder_input, labels, discrete_latent_z,
                          encoder_probs, encoder_entropy):
         batch_size, latent_size = encoder_probs.shape
-        _, rows, cols, _ = _native.support_compact(encoder_probs.detach(), want_vals=False,
-                                                      support_cols=F_.support_cols_of(encoder_probs))
+        off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
+                                                        support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         if rows_l.numel() == 0:
             raise RuntimeError("Marginalizer: the encoder distribution has no live category")
@@ -143,7 +143,8 @@ class Marginalizer(torch.nn.Module):
         loss_n, logs = self.loss(
             encoder_input_sel, discrete_latent_z[rows_l], decoder_input_sel, decoder_output,
             labels[rows_l])
-        probs_sel = encoder_probs[rows_l, cols_l]
+        # (the compaction wrote the selected probabilities; one scatter takes their gradient back)
+        probs_sel = F_.gather_support(encoder_probs, off, cols, vals)
         loss_mean = F_.weighted_loss(probs_sel, loss_n.to(encoder_probs.dtype), 1.0 / batch_size)
         for k, v in logs.items():
             if hasattr(v, 'mean'):   # sum_z (p[:, z] * v_z).mean() of the reference, marg.py:107-113
