@@ -797,6 +797,7 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
 // Fixed-shape, order-deterministic two-stage sum: stage 1 gives each of up to kRedBlocks blocks a
 // contiguous slice of the N products (fp64), stage 2 folds the partials in index order.
 constexpr int kRedBlocks = 1024;
+constexpr int64_t kRedSingle = 16384;   // up to here one block sums everything and writes the total itself
 
 __global__ __launch_bounds__(256) void wlr_rows_kernel(const float* __restrict__ vals,
                                                        const float* __restrict__ comps,
@@ -814,7 +815,8 @@ __global__ __launch_bounds__(256) void wlr_rows_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void wlr_partial_kernel(const float* __restrict__ vals,
                                                           const float* __restrict__ comps,
                                                           double* __restrict__ partials, int64_t N,
-                                                          int64_t per_block)
+                                                          int64_t per_block, float scale,
+                                                          float* __restrict__ total)
 {
     __shared__ double lds[4];
     const int64_t lo = (int64_t)blockIdx.x * per_block;
@@ -824,14 +826,20 @@ __global__ __launch_bounds__(256) void wlr_partial_kernel(const float* __restric
     acc = group_reduce<64>(acc, OpSum{});
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    if (threadIdx.x == 0) {
+        const double blk = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+        // a single block is the whole sum: the second stage's arithmetic, without its launch
+        if (total) total[0] = (float)(blk * (double)scale);
+        else partials[blockIdx.x] = blk;
+    }
 }
 
 // -sum_{v > 0} v log v over the compacted (or dense) distribution, same fixed two-stage shape
 // (structmarg.py:51-54, 200: `-(distr @ torch.log(distr))`, entries that are not positive skipped)
 __global__ __launch_bounds__(256) void plogp_partial_kernel(const float* __restrict__ vals,
                                                             double* __restrict__ partials, int64_t N,
-                                                            int64_t per_block)
+                                                            int64_t per_block, float scale,
+                                                            float* __restrict__ total)
 {
     __shared__ double lds[4];
     const int64_t lo = (int64_t)blockIdx.x * per_block;
@@ -844,7 +852,12 @@ __global__ __launch_bounds__(256) void plogp_partial_kernel(const float* __restr
     acc = group_reduce<64>(acc, OpSum{});
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+    if (threadIdx.x == 0) {
+        const double blk = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+        // a single block is the whole sum: the second stage's arithmetic, without its launch
+        if (total) total[0] = (float)(blk * (double)scale);
+        else partials[blockIdx.x] = blk;
+    }
 }
 
 // d/dv of -scale * sum v log v, times the incoming gradient: -(log v + 1) scale g for v > 0, else 0
@@ -1158,10 +1171,15 @@ extern "C" int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* co
         double* partials = (double*)workspace;
         int64_t per_block = (N + kRedBlocks - 1) / kRedBlocks;
         if (per_block < 256) per_block = 256;
+        if (N <= kRedSingle) per_block = N > 0 ? N : 1;   // one block, one launch
         int nparts = (int)((N + per_block - 1) / per_block);
-        if (nparts > 0)
-            hipLaunchKernelGGL(wlr_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, comps, partials, N, per_block);
-        hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, inv_b, total);
+        if (nparts == 1) {   // small N (model-shaped batches): one launch
+            hipLaunchKernelGGL(wlr_partial_kernel, dim3(1), dim3(256), 0, st, vals, comps, partials, N, per_block, inv_b, total);
+        } else {
+            if (nparts > 0)
+                hipLaunchKernelGGL(wlr_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, comps, partials, N, per_block, 0.0f, (float*)nullptr);
+            hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, inv_b, total);
+        }
     }
     return check_launch();
 }
@@ -1189,10 +1207,15 @@ extern "C" int smlvm_support_entropy_fwd(const float* vals, int64_t N, float inv
     double* partials = (double*)workspace;
     int64_t per_block = (N + kRedBlocks - 1) / kRedBlocks;
     if (per_block < 256) per_block = 256;
+    if (N <= kRedSingle) per_block = N > 0 ? N : 1;   // one block, one launch
     const int nparts = (int)((N + per_block - 1) / per_block);
-    if (nparts > 0)
-        hipLaunchKernelGGL(plogp_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, partials, N, per_block);
-    hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, -inv_b, total);
+    if (nparts == 1) {
+        hipLaunchKernelGGL(plogp_partial_kernel, dim3(1), dim3(256), 0, st, vals, partials, N, per_block, -inv_b, total);
+    } else {
+        if (nparts > 0)
+            hipLaunchKernelGGL(plogp_partial_kernel, dim3((unsigned)nparts), dim3(256), 0, st, vals, partials, N, per_block, 0.0f, (float*)nullptr);
+        hipLaunchKernelGGL(wlr_final_kernel, dim3(1), dim3(64), 0, st, partials, nparts, -inv_b, total);
+    }
     return check_launch();
 }
 
