@@ -287,7 +287,15 @@ int smlvm_unpack_configs(const uint32_t* aset_bits, const int32_t* rows, const i
  *   fwd outputs: lse [N,F] fp32 (saved for the backward), nll [N,F] fp32, loss [N] fp32 (nullable)
  *   bwd: gloss [N] = dL/dloss;  dx [N,F,R], dw [C,R], db [C] (each nullable); workspace of
  *        smlvm_lowrank_ce_bwd_workspace_bytes bytes for the per-block dw/db partials.
+ *   fwd_dxdir: the forward with one more output, dxdir [N,F,R] fp32 =
+ *        sum_c softmax(logits[n,f,:])_c w[c,:] - w[y[n,f],:], the gradient of loss[n] with respect to
+ *        x[n,f,:]: the training backward's dx is gloss[n] * dxdir[n,f,:] and `bwd` is then called
+ *        with dx = NULL (it costs the forward R packed FMAs more per logit and saves the backward a
+ *        whole pass of C exponentials per element).
  */
+int smlvm_lowrank_ce_fwd_dxdir(const float* x, const float* w, const float* b, const void* y,
+                               int32_t y_kind, float* lse, float* nll, float* loss, float* dxdir,
+                               int64_t N, int32_t F, int32_t C, int32_t R, void* stream);
 int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float* b, const void* y,
                          int32_t y_kind, float* lse, float* nll, float* loss, int64_t N, int32_t F,
                          int32_t C, int32_t R, void* stream);

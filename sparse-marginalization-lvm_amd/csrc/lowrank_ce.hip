@@ -76,12 +76,39 @@ __device__ float lse_exact(const f32x2 (&x)[R], int half, const float* __restric
     return fmaf(log2f(s), kLn2, mx);
 }
 
+// sum_c softmax_c W[c, :] - W[y, :] of one element, exactly (two passes; the underflow redo of DXD)
+template <int R>
+__device__ void dxdir_exact(const f32x2 (&x)[R], int half, const float* __restrict__ w,
+                            const float* __restrict__ b, int C, int yy, float* __restrict__ out)
+{
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, logit_at<R>(x, half, w, b, c));
+    float s = 0.0f, v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float e = ex2((logit_at<R>(x, half, w, b, c) - mx) * kLog2e);
+        s += e;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = fmaf(e, w[c * R + r], v[r]);
+    }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[r] = yy >= 0 ? v[r] * inv - w[yy * R + r] : __builtin_nanf("");
+}
+
 constexpr int kPixPerBlock = 512;
 
-template <int R, typename YT>
+// DXD (round 3): the pass that sums exp(logit - bound) also sums exp(logit - bound) W[c, :], R more
+// packed FMAs per class; divided by the first sum that is softmax . W, and
+//     dxdir[p, :] = sum_c softmax_c W[c, :] - W[y_p, :]
+// is the gradient of the element's loss with respect to x[p, :].  The backward's dX is then
+// gloss[n] * dxdir -- the dX kernel and its whole exp pass (one of the step's three) are gone.
+template <int R, typename YT, bool DXD>
 __global__ __launch_bounds__(256) void lowrank_ce_fwd_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ b,
-    const void* __restrict__ y, float* __restrict__ lse, float* __restrict__ nll, int64_t P, int C)
+    const void* __restrict__ y, float* __restrict__ lse, float* __restrict__ nll,
+    float* __restrict__ dxdir, int64_t P, int C)
 {
     // Upper bound of every logit of an element: max_c b_c + sum_r |x_r| max_c |W_cr|.  Shifting by
     // it (instead of by the exact maximum) saves the whole max pass; the sum cannot overflow, and
@@ -124,21 +151,42 @@ __global__ __launch_bounds__(256) void lowrank_ce_fwd_kernel(
     const f32x2 m2 = bound * kLog2e;
     const f32x2 k2 = splat(kLog2e);
     f32x2 s = splat(0.0f);
+    f32x2 V[DXD ? R : 1];
+#pragma unroll
+    for (int r = 0; r < (DXD ? R : 1); ++r) V[r] = splat(0.0f);
 #pragma unroll 8
     for (int c = 0; c < C; ++c) {
         const f32x2 t = fma2(logit2<R>(x, W, b, c), k2, -m2);
         f32x2 e = {ex2(t.x), ex2(t.y)};
         s += e;
+        if constexpr (DXD) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) V[r] = fma2(e, splat(W[c * R + r]), V[r]);
+        }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float sh = h ? s.y : s.x, bh = h ? bound.y : bound.x;
+        const bool redo = !(sh > 1e-18f);   // also catches NaN
         float L = fmaf(log2f(sh), kLn2, bh);
-        if (!(sh > 1e-18f)) L = lse_exact<R>(x, h, W, b, C);   // also catches NaN
+        if (redo) L = lse_exact<R>(x, h, W, b, C);
         if (live[h]) {
             const int yy = label_at<YT>(y, p[h], C);
             lse[p[h]] = L;
             nll[p[h]] = yy >= 0 ? L - logit_at<R>(x, h, W, b, yy) : __builtin_nanf("");
+            if constexpr (DXD) {
+                float* out = dxdir + p[h] * R;
+                if (redo) {
+                    dxdir_exact<R>(x, h, W, b, C, yy, out);
+                } else {
+                    const float inv = 1.0f / sh;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float v = h ? V[r].y : V[r].x;
+                        out[r] = yy >= 0 ? v * inv - W[yy * R + r] : __builtin_nanf("");
+                    }
+                }
+            }
         }
     }
 }
@@ -377,9 +425,9 @@ static int lr_check(int64_t N, int32_t F, int32_t C, int32_t R)
     return SMLVM_OK;
 }
 
-extern "C" int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float* b, const void* y,
-                                    int32_t y_kind, float* lse, float* nll, float* loss, int64_t N,
-                                    int32_t F, int32_t C, int32_t R, void* stream)
+static int lowrank_ce_fwd_go(const float* x, const float* w, const float* b, const void* y,
+                             int32_t y_kind, float* lse, float* nll, float* loss, float* dxdir,
+                             int64_t N, int32_t F, int32_t C, int32_t R, void* stream)
 {
     const int rc = lr_check(N, F, C, R);
     if (rc != SMLVM_OK) return rc;
@@ -388,13 +436,35 @@ extern "C" int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float*
     const int64_t P = N * F;
     const unsigned grid = (unsigned)((P + kPixPerBlock - 1) / kPixPerBlock);
     hipStream_t st = (hipStream_t)stream;
-    SMLVM_LR_DISPATCH_R(R, SMLVM_LR_DISPATCH_Y(y_kind,
-        hipLaunchKernelGGL((lowrank_ce_fwd_kernel<RR, YY>), dim3(grid), dim3(256), 0, st, x, w, b, y,
-                           lse, nll, P, C)));
+    if (dxdir) {
+        SMLVM_LR_DISPATCH_R(R, SMLVM_LR_DISPATCH_Y(y_kind,
+            hipLaunchKernelGGL((lowrank_ce_fwd_kernel<RR, YY, true>), dim3(grid), dim3(256), 0, st, x, w, b, y,
+                               lse, nll, dxdir, P, C)));
+    } else {
+        SMLVM_LR_DISPATCH_R(R, SMLVM_LR_DISPATCH_Y(y_kind,
+            hipLaunchKernelGGL((lowrank_ce_fwd_kernel<RR, YY, false>), dim3(grid), dim3(256), 0, st, x, w, b, y,
+                               lse, nll, (float*)nullptr, P, C)));
+    }
     int rc2 = check_launch();
     if (rc2 != SMLVM_OK || !loss) return rc2;
     hipLaunchKernelGGL(row_sum_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, nll, loss, N, F);
     return check_launch();
+}
+
+extern "C" int smlvm_lowrank_ce_fwd(const float* x, const float* w, const float* b, const void* y,
+                                    int32_t y_kind, float* lse, float* nll, float* loss, int64_t N,
+                                    int32_t F, int32_t C, int32_t R, void* stream)
+{
+    return lowrank_ce_fwd_go(x, w, b, y, y_kind, lse, nll, loss, nullptr, N, F, C, R, stream);
+}
+
+extern "C" int smlvm_lowrank_ce_fwd_dxdir(const float* x, const float* w, const float* b, const void* y,
+                                          int32_t y_kind, float* lse, float* nll, float* loss,
+                                          float* dxdir, int64_t N, int32_t F, int32_t C, int32_t R,
+                                          void* stream)
+{
+    if (N > 0 && !dxdir) return SMLVM_ERR_INVALID;
+    return lowrank_ce_fwd_go(x, w, b, y, y_kind, lse, nll, loss, dxdir, N, F, C, R, stream);
 }
 
 extern "C" size_t smlvm_lowrank_ce_bwd_workspace_bytes(int64_t N, int32_t F, int32_t C, int32_t R)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "smlvm_binary_topk_batched", "smlvm_sparsemap_fwd_workspace_bytes", "smlvm_sparsemap_fwd",
     "smlvm_sparsemap_bwd", "smlvm_sparsemap_seq_fwd", "smlvm_sparsemap_seq_bwd",
     "smlvm_unpack_configs",
-    "smlvm_lowrank_ce_fwd", "smlvm_lowrank_ce_bwd_workspace_bytes", "smlvm_lowrank_ce_bwd",
+    "smlvm_lowrank_ce_fwd", "smlvm_lowrank_ce_fwd_dxdir", "smlvm_lowrank_ce_bwd_workspace_bytes", "smlvm_lowrank_ce_bwd",
     "smlvm_segmented_logsumexp",
 ]
 
@@ -569,8 +569,9 @@ def _labels(y, N, F):
     return y, _Y_KINDS[y.dtype]
 
 
-def lowrank_ce_fwd(x, w, b, y):
-    """x [N,F,R] f32, w [C,R] f32, b [C] f32, y [N,F] labels -> (loss [N], lse [N,F], nll [N,F])."""
+def lowrank_ce_fwd(x, w, b, y, want_dxdir=False):
+    """x [N,F,R] f32, w [C,R] f32, b [C] f32, y [N,F] labels -> (loss [N], lse [N,F], nll [N,F]);
+    want_dxdir=True appends dxdir [N,F,R] = d loss[n] / d x[n,f,:] (smlvm_lowrank_ce_fwd_dxdir)."""
     x = _need_gpu(x, torch.float32, "x")
     w = _need_gpu(w, torch.float32, "w")
     b = _need_gpu(b, torch.float32, "b")
@@ -583,6 +584,13 @@ def lowrank_ce_fwd(x, w, b, y):
     lse = torch.empty((N, F), dtype=torch.float32, device=dev)
     nll = torch.empty((N, F), dtype=torch.float32, device=dev)
     loss = torch.empty(N, dtype=torch.float32, device=dev)
+    if want_dxdir:
+        dxdir = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _check(lib().smlvm_lowrank_ce_fwd_dxdir(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(nll),
+                                                    _p(loss), _p(dxdir), _i64(N), _i32(F), _i32(C), _i32(R),
+                                                    _stream()), "smlvm_lowrank_ce_fwd_dxdir")
+        return loss, lse, nll, dxdir
     with torch.cuda.device(dev):
         _check(lib().smlvm_lowrank_ce_fwd(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(nll),
                                           _p(loss), _i64(N), _i32(F), _i32(C), _i32(R), _stream()),

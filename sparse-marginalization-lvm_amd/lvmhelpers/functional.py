@@ -181,17 +181,30 @@ class _LowRankCE(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, y):
-        loss, lse, _ = _native.lowrank_ce_fwd(x, w, b, y)
-        ctx.save_for_backward(x, w, b, y, lse)
+        # when x wants a gradient the forward pass also leaves d loss / d x (R packed FMAs more per
+        # logit): the backward's dX is then an elementwise product, not a third pass of exponentials
+        ctx.has_dxdir = bool(ctx.needs_input_grad[0]) and x.numel() > 0
+        if ctx.has_dxdir:
+            loss, lse, _, dxdir = _native.lowrank_ce_fwd(x, w, b, y, want_dxdir=True)
+            ctx.save_for_backward(x, w, b, y, lse, dxdir)
+        else:
+            loss, lse, _ = _native.lowrank_ce_fwd(x, w, b, y)
+            ctx.save_for_backward(x, w, b, y, lse)
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
-        x, w, b, y, lse = ctx.saved_tensors
-        dx, dw, db = _native.lowrank_ce_bwd(
-            x, w, b, y, lse, gloss.contiguous().to(torch.float32),
-            want_dx=ctx.needs_input_grad[0],
-            want_dw=ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        x, w, b, y, lse = ctx.saved_tensors[:5]
+        gloss = gloss.contiguous().to(torch.float32)
+        want_dw = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if ctx.has_dxdir:
+            dx = ctx.saved_tensors[5] * gloss.view(-1, 1, 1) if ctx.needs_input_grad[0] else None
+            dw = db = None
+            if want_dw:
+                _, dw, db = _native.lowrank_ce_bwd(x, w, b, y, lse, gloss, want_dx=False, want_dw=True)
+            return dx, dw, db, None
+        dx, dw, db = _native.lowrank_ce_bwd(x, w, b, y, lse, gloss,
+                                            want_dx=ctx.needs_input_grad[0], want_dw=want_dw)
         return dx, dw, db, None
 
 

@@ -55,6 +55,30 @@ def test_lowrank_nll_matches_reference(dev, N, Fe, C, R, ydtype, scale):
         assert float((got.cpu().double() - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("N,Fe,C,R,scale", [(7, 784, 256, 5, 1.0), (3, 784, 256, 5, 3.0), (4, 50, 256, 5, 40.0),
+                                            (2, 100, 256, 8, 0.1), (1, 1, 2, 3, 1.0), (64, 17, 200, 4, 1.0)])
+def test_forward_dx_direction_equals_the_dx_kernel(dev, N, Fe, C, R, scale):
+    """smlvm_lowrank_ce_fwd_dxdir: the forward's extra output times gloss is the dX that the backward
+    kernel recomputes from the saved log-sum-exp (incl. logits so large that the bound-shifted sums
+    underflow and the element is redone exactly), and the other outputs do not change."""
+    from lvmhelpers import _native
+    x, w, b, y, gl = _problem(N, Fe, C, R, 77 + N, torch.uint8 if C <= 256 else torch.int64, scale)
+    xd, wd, bd, yd, gd = x.to(dev), w.to(dev), b.to(dev), y.to(dev), gl.to(dev)
+    loss0, lse0, nll0 = _native.lowrank_ce_fwd(xd, wd, bd, yd)
+    loss1, lse1, nll1, dxdir = _native.lowrank_ce_fwd(xd, wd, bd, yd, want_dxdir=True)
+    assert torch.equal(loss0, loss1) and torch.equal(lse0, lse1) and torch.equal(nll0, nll1)
+    dx_k, _, _ = _native.lowrank_ce_bwd(xd, wd, bd, yd, lse0, gd, want_dx=True, want_dw=False)
+    dx_f = dxdir * gd.view(-1, 1, 1)
+    _, dx_ref, _, _ = _ref64(x, w, b, y, gl)
+    top = max(1.0, float(dx_ref.abs().max()))
+    # measured against fp64: 6e-7 / 1.5e-6 / 3.8e-6 of the largest entry at scales 1 / 3 / 40 (the
+    # kernel that recomputes softmax = exp(logit - lse) in fp32: 1.4e-6 / 5.6e-6 / 3e-4 -- with logits
+    # in the thousands that difference cancels badly; the forward's ratio of two sums does not)
+    assert float((dx_f.cpu().double() - dx_ref).abs().max()) <= 1e-5 * top
+    if scale <= 3.0:
+        assert float((dx_f - dx_k).abs().max()) <= 2e-5 * top
+
+
 def test_fused_generator_is_a_drop_in(dev):
     """Same state_dict keys and same loss/gradients as the reference pair
     CategoricalGenerator + reconstruction_loss (archs.py:18-29, train.py:361-371), whose dense

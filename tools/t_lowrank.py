@@ -34,6 +34,10 @@ def ms(f, n=10, wu=3):
 
 loss, lse, nll = _native.lowrank_ce_fwd(x, w, b, y)
 print(f"N={N}: fwd {ms(lambda: _native.lowrank_ce_fwd(x, w, b, y)):.3f} ms", flush=True)
+print(f"  fwd + dx direction {ms(lambda: _native.lowrank_ce_fwd(x, w, b, y, want_dxdir=True)):.3f} ms", flush=True)
+_dd = _native.lowrank_ce_fwd(x, w, b, y, want_dxdir=True)[3]
+print(f"  dx = gloss * dxdir (torch) {ms(lambda: _dd * gl.view(-1, 1, 1)):.3f} ms", flush=True)
+del _dd
 print(f"  bwd dx only {ms(lambda: _native.lowrank_ce_bwd(x, w, b, y, lse, gl, True, False)):.3f} ms", flush=True)
 print(f"  bwd dw only {ms(lambda: _native.lowrank_ce_bwd(x, w, b, y, lse, gl, False, True)):.3f} ms", flush=True)
 print(f"  bwd both    {ms(lambda: _native.lowrank_ce_bwd(x, w, b, y, lse, gl, True, True)):.3f} ms", flush=True)
