@@ -555,7 +555,9 @@ __device__ __forceinline__ long long block_exclusive_scan_nw(long long v, long l
     return base + inc - v;
 }
 
-template <int G, bool VEC>
+// LR: no lists at all and K <= 64 -- a lane per row (below); a variant of its own, so that the
+// list-fed kernel keeps the code it was tuned with (as a run-time branch it cost that one 8 %)
+template <int G, bool VEC, bool LR = false>
 __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel(
     const float* __restrict__ p, const int32_t* __restrict__ lists, const float* __restrict__ vlists,
     int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows, int32_t* __restrict__ cols,
@@ -620,8 +622,8 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
     // [B, k] top-k distribution): a lane per row.  A wave per row, one row after the other, is 128
     // dependent round trips for a tile of 64 rows -- 47 us for the 64 x 33 batch of the 32-bit VAE,
     // which the host then waits for (it reads the offsets back).
-    const bool lane_rows = lists == nullptr && K <= 64;
-    if (lane_rows) {
+    constexpr bool lane_rows = LR;
+    if constexpr (lane_rows) {
         const int64_t r = row_base + lane;
         int c = 0;
         if (r < R) {
@@ -765,14 +767,14 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
                 }
             }
         }
-        if (lane_rows) continue;
+        if constexpr (lane_rows) continue;
         for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
             const int g = __builtin_ctzll(todo) / G;
             const int64_t r = row_base + s * RW + g;
             compact_row_scan_lim<VEC>(p + r * K, K, lane, r, offs[wave * 64 + s * RW + g], n_cap, rows, cols, vals);
         }
     }
-    if (lane_rows) {
+    if constexpr (lane_rows) {
         const int64_t r = row_base + lane;
         if (r < R) {
             int64_t pos = offs[wave * 64 + lane];
@@ -1140,7 +1142,10 @@ extern "C" int smlvm_support_compact_fused(const float* p, const int32_t* suppor
 #define SMLVM_FUSED(G)                                                                                      \
     if (vec) hipLaunchKernelGGL((support_compact_fused_kernel<G, true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws); \
     else hipLaunchKernelGGL((support_compact_fused_kernel<G, false>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws)
-    if (support_cols && cap == 16) { SMLVM_FUSED(4); }
+    if (!support_cols && K <= 64) {
+        hipLaunchKernelGGL((support_compact_fused_kernel<8, false, true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws);
+    }
+    else if (support_cols && cap == 16) { SMLVM_FUSED(4); }
     else if (support_cols && cap == 64) { SMLVM_FUSED(16); }
     else { SMLVM_FUSED(8); }
 #undef SMLVM_FUSED
