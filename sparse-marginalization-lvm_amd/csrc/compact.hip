@@ -632,6 +632,37 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
             for (int k = 0; k < K; ++k) c += pr[k] > 0.0f ? 1 : 0;
         }
         cnt[wave * 64 + lane] = c;
+    } else if (VEC && G <= 8 && K <= 256) {
+        // short rows without a list (narrow logits: more non-zeros than a list holds), four at a
+        // time with their loads in flight together -- one row after the other, each a dependent
+        // round trip, made 1M x 256 rows of N(0, 0.05^2) latency bound (0.65 ms)
+        const int K4 = K >> 2;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            for (unsigned long long todo = unl_steps[s]; todo != 0ull;) {   // wave-uniform
+                int g[4], n = 0;
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[u] = 0;
+                    if (todo != 0ull) {
+                        g[u] = __builtin_ctzll(todo) / G;
+                        todo &= todo - 1ull;
+                        n = u + 1;
+                        if (lane < K4) v[u] = reinterpret_cast<const float4*>(p + (row_base + s * RW + g[u]) * K)[lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < n) {
+                        int c = (v[u].x > 0.0f) + (v[u].y > 0.0f) + (v[u].z > 0.0f) + (v[u].w > 0.0f);
+                        c = group_reduce<64>(c, OpSum{});
+                        if (lane == 0) cnt[wave * 64 + s * RW + g[u]] = c;
+                    }
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -768,6 +799,32 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
             }
         }
         if constexpr (lane_rows) continue;
+        if (VEC && G <= 8 && K <= 256) {   // four short rows at a time, as in phase A
+            const int K4 = K >> 2;
+            for (unsigned long long todo = unl_steps[s]; todo != 0ull;) {   // wave-uniform
+                int g[4], n = 0;
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    g[u] = 0;
+                    if (todo != 0ull) {
+                        g[u] = __builtin_ctzll(todo) / G;
+                        todo &= todo - 1ull;
+                        n = u + 1;
+                        if (lane < K4) v[u] = reinterpret_cast<const float4*>(p + (row_base + s * RW + g[u]) * K)[lane];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u < n) {
+                        int64_t out = offs[wave * 64 + s * RW + g[u]];
+                        compact_step4_lim(v[u], lane, row_base + s * RW + g[u], out, n_cap, rows, cols, vals);
+                    }
+                }
+            }
+            continue;
+        }
         for (unsigned long long todo = unl_steps[s]; todo != 0ull; todo &= todo - 1ull) {   // wave-uniform
             const int g = __builtin_ctzll(todo) / G;
             const int64_t r = row_base + s * RW + g;
