@@ -107,6 +107,17 @@ int smlvm_entropy(const float* p, float* ent, int64_t R, int32_t K, void* stream
  * K <= 65536 (SMLVM_ERR_UNSUPPORTED beyond). */
 int smlvm_entmax15_fwd(const float* x, float* p, int32_t* nnz, float* tau, int64_t R, int32_t K,
                        void* stream);
+/* The same pair with support lists, for rows held by one wave (512 < K <= 4096; SMLVM_ERR_UNSUPPORTED
+ * otherwise): the forward also writes support_cols [R, cap] int32 (columns with p > 0, -1 padding,
+ * -2 in slot 0 = no list: more than cap non-zeros, or a row whose threshold search ran full width)
+ * and support_vals [R, cap] fp32 = sqrt(p) of the listed columns, slot for slot; 1 <= cap <= 64.  The
+ * backward gathers dy at the listed columns, writes dx = sqrt(p) (dy - q) there and zeros elsewhere,
+ * and reads p only for rows without a list (same Entmax15Function.backward, O(support) reads). */
+int smlvm_entmax15_fwd_lists(const float* x, float* p, int32_t* nnz, float* tau, int32_t* support_cols,
+                             float* support_vals, int32_t cap, int64_t R, int32_t K, void* stream);
+int smlvm_entmax15_bwd_lists(const float* dy, const float* p, const int32_t* support_cols,
+                             const float* support_vals, int32_t cap, float* dx, int64_t R, int32_t K,
+                             void* stream);
 int smlvm_entmax15_bwd(const float* dy, const float* p, float* dx, int64_t R, int32_t K,
                        void* stream);
 

@@ -1670,6 +1670,39 @@ __device__ __forceinline__ void bwd_row_assemble(const float* __restrict__ dyrow
     }
 }
 
+// The same assembly with a weight per listed column (entmax15: w = sqrt(p)): the row's dx is
+// w (dy - q) at the listed columns, q = sum dy w / sum w, zero elsewhere.
+template <int E>
+__device__ __forceinline__ void bwd_row_assemble_weighted(const float* __restrict__ dyrow,
+                                                          float* __restrict__ dxrow, int c0, float w0,
+                                                          int K, int lane, bool live, WaveRed<64>& red,
+                                                          float* wl)
+{
+    float* tile = wl;
+    float4* tile4 = reinterpret_cast<float4*>(tile);
+    float v0 = 0.0f;
+    if (c0 >= 0) v0 = dyrow[c0];
+    const double A = red.sum((double)(v0 * w0)), B = red.sum((double)w0);
+    const float q = (float)(A / B);
+    v0 = (v0 - q) * w0;
+    float4* dx4 = reinterpret_cast<float4*>(dxrow);
+    const int K4 = K >> 2;
+#pragma unroll
+    for (int qq = 0; qq < E / 16; ++qq) {
+        const bool h0 = c0 >= 0 && (c0 >> 10) == qq;
+        if (h0) tile[c0 & (kPatTile - 1)] = v0;
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < kPatTile / 256; ++i) {
+            const float4 t = tile4[i * 64 + lane];
+            const int f = qq * (kPatTile / 4) + i * 64 + lane;   // float4 index in the row
+            if (live && f < K4) nt_store4(dx4 + f, t);
+        }
+        wave_lds_sync();
+        if (h0) tile[c0 & (kPatTile - 1)] = 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------- kernels
 constexpr int kWavesPerBlock = 4;
 
@@ -2633,9 +2666,13 @@ __device__ __forceinline__ float entmax15_closed_form(const float (&v)[N], float
 // ~10 steps and the closed form run on 4 values per lane instead of 64, without workgroup barriers
 // (every wave of a workgroup holds the same list).  Rows whose sets stay wide (narrow logit
 // distributions) iterate full width as before.
+// list != nullptr (NW == 1 only): the row's support list -- columns with p > 0, and at byte distance
+// vdelta the values sqrt(p) = z - tau slot for slot (what the backward weighs with) -- comes from the
+// candidates; rows that finished full width are marked kColsOverflow (their backward reads p).
 template <int E, int NW, bool VEC, class Red>
 __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_out, float& tau_out,
-                                             float* cand = nullptr)
+                                             float* cand = nullptr, int32_t* list = nullptr, int cap = 0,
+                                             bool live = true, long long vdelta = 0)
 {
     float mx = z[0];
 #pragma unroll
@@ -2646,6 +2683,9 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
     float tau = -1.0f;
     bool listed = false;
     float c[kCandPerLane];
+    int cc[kCandPerLane];
+#pragma unroll
+    for (int q = 0; q < kCandPerLane; ++q) cc[q] = 0;
     // attempt the compaction once the bound says the set may fit (for a tail of N(0,1) logits the
     // set is about twice the bound); after a failure, when the bound has halved
     float try_below = 0.4f * (float)kCandCap;
@@ -2661,10 +2701,16 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
             if (cnt <= try_below) {                  // wave- (NW == 1) / workgroup-uniform
                 const int lane = threadIdx.x & 63;
                 if constexpr (NW == 1) {
-                    const int n_c = compact_candidates<E, VEC>(z, tau, cand, kCandCap, nullptr, 0, 0);
+                    int* ccols = list ? reinterpret_cast<int*>(cand + kCandCap) : nullptr;
+                    const int n_c = compact_candidates<E, VEC>(z, tau, cand, kCandCap, ccols, VEC ? lane * 4 : lane,
+                                                               VEC ? 256 : 64);
                     wave_lds_sync();
 #pragma unroll
-                    for (int q = 0; q < kCandPerLane; ++q) c[q] = (lane + 64 * q < n_c) ? cand[lane + 64 * q] : -INFINITY;
+                    for (int q = 0; q < kCandPerLane; ++q) {
+                        const bool have = lane + 64 * q < n_c;
+                        c[q] = have ? cand[lane + 64 * q] : -INFINITY;
+                        cc[q] = (have && list) ? ccols[lane + 64 * q] : 0;
+                    }
                     wave_lds_sync();
                     listed = n_c <= kCandCap;
                 } else {
@@ -2716,6 +2762,13 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
         }
     }
     if (!listed) tau = entmax15_closed_form(z, tau, red);
+    if constexpr (NW == 1) {
+        if (list) {
+            const int lane = threadIdx.x & 63;
+            if (listed) emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau, lane, 0, list, cap, live, kColsOverflow, vdelta);
+            else if (live && lane == 0) list[0] = kColsOverflow;
+        }
+    }
     int n = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -2748,7 +2801,8 @@ __device__ __forceinline__ void entmax15_bwd_row(float (&g)[E], const float (&y)
 template <int G, int E, bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 5 : 4) void entmax15_fwd_wave_kernel(
     const float* __restrict__ x, float* __restrict__ p, int32_t* __restrict__ nnz,
-    float* __restrict__ tau, int64_t R, int K)
+    float* __restrict__ tau, int64_t R, int K, int32_t* __restrict__ cols = nullptr, int cap = 0,
+    long long vdelta = 0)
 {
     const int lane = threadIdx.x & 63, gl = lane % G;
     int64_t row = wave_row<G>(lane);
@@ -2759,9 +2813,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 5 : 4) void entmax15
     WaveRed<G> red;
     int n;
     float t;
-    constexpr bool CAND = (G == 64);   // one row per wave: a candidate list per wave
-    __shared__ float cand[CAND ? kWavesPerBlock * kCandCap : 1];
-    entmax15_row<E, CAND ? 1 : 0, VEC>(z, red, n, t, cand + (CAND ? (threadIdx.x >> 6) * kCandCap : 0));
+    constexpr bool CAND = (G == 64);   // one row per wave: a candidate list (values, columns) per wave
+    __shared__ float cand[CAND ? kWavesPerBlock * 2 * kCandCap : 1];
+    if constexpr (CAND)
+        entmax15_row<E, 1, VEC>(z, red, n, t, cand + (threadIdx.x >> 6) * 2 * kCandCap,
+                                cols ? cols + row * cap : nullptr, cap, live, vdelta);
+    else
+        entmax15_row<E, 0, VEC>(z, red, n, t);
     if (live) {
         store_row<E, VEC, FULL>(p + row * K, K, gl, G, z);
         if (gl == 0) {
@@ -2811,6 +2869,62 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 4 : 2) void entmax15
     if (live) store_row<E, VEC, FULL>(dx + row * K, K, gl, G, g);
 }
 
+// Rows of one wave (512 < K <= 4096) with the forward's lists: columns of the support and the
+// weights r = sqrt(p) = z - tau.  dx = r (dy - q) at the listed columns, q = sum dy r / sum r, zero
+// elsewhere: the row of dy is gathered at <= cap places, p is not read, dx is zero-filled and the
+// few values follow once the fill is acknowledged (the same two rounds of stores as sparsemax's
+// first list backward).  Rows marked kColsOverflow read p and dy as entmax15_bwd_wave_kernel does.
+template <int E, bool VEC, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 4 : 2) void entmax15_bwd_cols_wave_kernel(
+    const float* __restrict__ dy, const float* __restrict__ p, const int32_t* __restrict__ cols,
+    const float* __restrict__ rvals, int cap, float* __restrict__ dx, int64_t R, int K)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t row = wave_row<64>(lane);
+    const bool live = row < R;
+    if (!live) row = R - 1;
+    WaveRed<64> red;
+    const int c = lane < cap ? cols[row * cap + lane] : kColsNone;
+    if (__builtin_amdgcn_readfirstlane(c) < kColsNone) {   // no list: the p-based backward
+        float g[E], y[E];
+        load_row<E, VEC, FULL>(p + row * K, K, lane, 64, y, 0.0f);
+        load_row<E, VEC, FULL>(dy + row * K, K, lane, 64, g, 0.0f);
+        entmax15_bwd_row(g, y, red);
+        if (live) store_row<E, VEC, FULL>(dx + row * K, K, lane, 64, g);
+        return;
+    }
+    float* dxrow = dx + row * K;
+    if constexpr (VEC) {
+        // 16-byte rows: dx assembled 1024 columns at a time in the wave's LDS tile and written once
+        // with full-width stores, like sparsemax's list backward (zero fill, wait, scattered
+        // 4-byte stores: 4.43 ms at 1M x 4096 against the p-based 8.56 ms; assembled: see DESIGN)
+        __shared__ __align__(16) float pat_lds[kWavesPerBlock * kPatLdsWords];
+        float* wl = pat_lds + (threadIdx.x >> 6) * kPatLdsWords;
+        float4* tile4 = reinterpret_cast<float4*>(wl);
+#pragma unroll
+        for (int i = 0; i < kPatTile / 256; ++i) tile4[i * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float w = c >= 0 ? rvals[row * cap + lane] : 0.0f;
+        bwd_row_assemble_weighted<E>(dy + row * K, dxrow, c, w, K, lane, live, red, wl);
+        return;
+    }
+    if (live) {
+        float zero[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) zero[e] = 0.0f;
+        store_row<E, VEC, FULL>(dxrow, K, lane, 64, zero);
+    }
+    float r = 0.0f, g = 0.0f;
+    if (c >= 0) {
+        r = rvals[row * cap + lane];
+        g = dy[row * K + c];
+    }
+    const double A = red.sum((double)(g * r)), B = red.sum((double)r);
+    const float q = (float)(A / B);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (live && c >= 0) dxrow[c] = (g - q) * r;
+}
+
 template <int NW, int E, bool VEC, bool FULL>
 __global__ __launch_bounds__(64 * NW) void entmax15_bwd_block_kernel(
     const float* __restrict__ dy, const float* __restrict__ p, float* __restrict__ dx, int64_t R, int K)
@@ -2838,6 +2952,10 @@ struct E15Args {
     int K;
     hipStream_t st;
     bool vec;
+    int32_t* cols = nullptr;       // forward: support lists to write / backward: to read
+    const float* rvals = nullptr;  // backward: sqrt(p) of the listed columns
+    int cap = 0;
+    long long vdelta = 0;          // forward: byte distance from the column list to the value list
 };
 
 #define SMLVM_E15_MODES(GO, A, E)                                                \
@@ -2852,8 +2970,19 @@ template <int G, int E, bool VEC, bool FULL>
 static void e15_fwd_wave_go(const E15Args& a)
 {
     hipLaunchKernelGGL((entmax15_fwd_wave_kernel<G, E, VEC, FULL>), dim3(wave_grid(a.R, G)),
-                       dim3(64 * kWavesPerBlock), 0, a.st, a.in0, a.out, a.nnz, a.tau, a.R, a.K);
+                       dim3(64 * kWavesPerBlock), 0, a.st, a.in0, a.out, a.nnz, a.tau, a.R, a.K,
+                       G == 64 ? a.cols : nullptr, a.cap, a.vdelta);
 }
+template <int G, int E, bool VEC, bool FULL>
+static void e15_bwd_cols_go(const E15Args& a)
+{
+    if constexpr (G == 64)
+        hipLaunchKernelGGL((entmax15_bwd_cols_wave_kernel<E, VEC, FULL>), dim3(wave_grid(a.R, 64)),
+                           dim3(64 * kWavesPerBlock), 0, a.st, a.in0, a.in1, a.cols, a.rvals, a.cap, a.out,
+                           a.R, a.K);
+}
+template <int NW, int E, bool VEC, bool FULL>
+static void e15_bwd_cols_block_go(const E15Args&) {}   // (never dispatched: lists are for one-wave rows)
 template <int NW, int E, bool VEC, bool FULL>
 static void e15_fwd_block_go(const E15Args& a)
 {
@@ -2876,6 +3005,8 @@ template <int A, int E> static void launch_e15_fwd_wave(const E15Args& a) { SMLV
 template <int A, int E> static void launch_e15_fwd_block(const E15Args& a) { SMLVM_E15_MODES(e15_fwd_block_go, A, E); }
 template <int A, int E> static void launch_e15_bwd_wave(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_wave_go, A, E); }
 template <int A, int E> static void launch_e15_bwd_block(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_block_go, A, E); }
+template <int A, int E> static void launch_e15_bwd_cols(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_cols_go, A, E); }
+template <int A, int E> static void launch_e15_bwd_cols_block(const E15Args& a) { SMLVM_E15_MODES(e15_bwd_cols_block_go, A, E); }
 
 }  // namespace smlvm
 
@@ -2989,6 +3120,41 @@ extern "C" int smlvm_entmax15_fwd(const float* x, float* p, int32_t* nnz, float*
     if (!x || !p) return SMLVM_ERR_INVALID;
     E15Args a{x, nullptr, p, nnz, tau, R, K, (hipStream_t)stream, (K % 4 == 0) && aligned16(x) && aligned16(p)};
     SMLVM_DISPATCH(launch_e15_fwd_wave, launch_e15_fwd_block, a);
+    return check_launch();
+}
+
+// Rows held by one wave (512 < K <= 4096): the forward also writes each row's support list and the
+// weights sqrt(p) of its entries; the backward then gathers dy at those columns and never reads p.
+extern "C" int smlvm_entmax15_fwd_lists(const float* x, float* p, int32_t* nnz, float* tau,
+                                        int32_t* support_cols, float* support_vals, int32_t cap,
+                                        int64_t R, int32_t K, void* stream)
+{
+    if (R < 0 || K < 1 || cap < 1 || cap > kColsMaxCap) return SMLVM_ERR_INVALID;
+    if (K <= 512 || K > 4096) return SMLVM_ERR_UNSUPPORTED;
+    if (R == 0) return SMLVM_OK;
+    if (!x || !p || !support_cols || !support_vals) return SMLVM_ERR_INVALID;
+    E15Args a{x, nullptr, p, nnz, tau, R, K, (hipStream_t)stream, (K % 4 == 0) && aligned16(x) && aligned16(p)};
+    a.cols = support_cols;
+    a.cap = cap;
+    a.vdelta = (long long)(reinterpret_cast<const char*>(support_vals) - reinterpret_cast<const char*>(support_cols));
+    SMLVM_DISPATCH(launch_e15_fwd_wave, launch_e15_fwd_block, a);
+    return check_launch();
+}
+
+extern "C" int smlvm_entmax15_bwd_lists(const float* dy, const float* p, const int32_t* support_cols,
+                                        const float* support_vals, int32_t cap, float* dx, int64_t R,
+                                        int32_t K, void* stream)
+{
+    if (R < 0 || K < 1 || cap < 1 || cap > kColsMaxCap) return SMLVM_ERR_INVALID;
+    if (K <= 512 || K > 4096) return SMLVM_ERR_UNSUPPORTED;
+    if (R == 0) return SMLVM_OK;
+    if (!dy || !p || !dx || !support_cols || !support_vals) return SMLVM_ERR_INVALID;
+    E15Args a{dy, p, dx, nullptr, nullptr, R, K, (hipStream_t)stream,
+              (K % 4 == 0) && aligned16(dy) && aligned16(p) && aligned16(dx)};
+    a.cols = const_cast<int32_t*>(support_cols);
+    a.rvals = support_vals;
+    a.cap = cap;
+    SMLVM_DISPATCH(launch_e15_bwd_cols, launch_e15_bwd_cols_block, a);
     return check_launch();
 }
 

@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error",
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy", "smlvm_entmax15_fwd", "smlvm_entmax15_bwd",
+    "smlvm_entmax15_fwd_lists", "smlvm_entmax15_bwd_lists",
     "smlvm_support_count", "smlvm_support_offsets_workspace_bytes", "smlvm_support_offsets",
     "smlvm_support_offsets_noalloc",
     "smlvm_sparsemax_support_mask_bytes", "smlvm_support_compact", "smlvm_support_count_cols", "smlvm_support_compact_cols",
@@ -203,6 +204,42 @@ def entmax15_fwd(x, want_nnz=False, want_tau=False):
         _check(lib().smlvm_entmax15_fwd(_p(x), _p(p), _p(nnz), _p(tau), _i64(R), _i32(K), _stream()),
                "smlvm_entmax15_fwd")
     return p, nnz, tau
+
+
+ENTMAX15_LIST_CAP = 64   # slots per row of entmax15's support lists (its supports are ~4x sparsemax's)
+
+
+def entmax15_has_lists(K):
+    """The list-carrying pair exists for rows held by one wave."""
+    return 512 < K <= 4096
+
+
+def entmax15_fwd_lists(x, cap=ENTMAX15_LIST_CAP):
+    """x [R,K], 512 < K <= 4096 -> (p, support_cols [R,cap] i32, support_vals [R,cap] f32 = sqrt(p))."""
+    x = _need_gpu(x, torch.float32, "x")
+    R, K = x.shape
+    p = torch.empty_like(x)
+    cols = torch.empty((R, cap), dtype=torch.int32, device=x.device)
+    vals = torch.empty((R, cap), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _check(lib().smlvm_entmax15_fwd_lists(_p(x), _p(p), None, None, _p(cols), _p(vals), _i32(cap),
+                                              _i64(R), _i32(K), _stream()), "smlvm_entmax15_fwd_lists")
+    return p, cols, vals
+
+
+def entmax15_bwd_lists(dy, p, cols, vals):
+    dy = _need_gpu(dy, torch.float32, "dy")
+    p = _need_gpu(p, torch.float32, "p")
+    cols = _need_gpu(cols, torch.int32, "support_cols")
+    vals = _need_gpu(vals, torch.float32, "support_vals")
+    R, K = p.shape
+    if tuple(cols.shape) != tuple(vals.shape) or cols.shape[0] != R:
+        raise ValueError("support_cols / support_vals must be [R, cap]")
+    dx = torch.empty_like(p)
+    with torch.cuda.device(p.device):
+        _check(lib().smlvm_entmax15_bwd_lists(_p(dy), _p(p), _p(cols), _p(vals), _i32(cols.shape[1]), _p(dx),
+                                              _i64(R), _i32(K), _stream()), "smlvm_entmax15_bwd_lists")
+    return dx
 
 
 def entmax15_bwd(dy, p):

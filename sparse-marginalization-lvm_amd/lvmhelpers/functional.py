@@ -31,14 +31,23 @@ class _Entmax15(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         shape = x.shape
-        p, _, _ = _native.entmax15_fwd(x.reshape(-1, shape[-1]))
-        ctx.save_for_backward(p)
+        x2 = x.reshape(-1, shape[-1])
+        ctx.listed = _native.entmax15_has_lists(shape[-1]) and x2.shape[0] > 0
+        if ctx.listed:   # rows of one wave: the forward leaves each row's support list and sqrt(p)
+            p, cols, vals = _native.entmax15_fwd_lists(x2)
+            ctx.save_for_backward(p, cols, vals)
+        else:
+            p, _, _ = _native.entmax15_fwd(x2)
+            ctx.save_for_backward(p)
         return p.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        (p,) = ctx.saved_tensors
-        return _native.entmax15_bwd(dy.reshape(p.shape).contiguous(), p).view(dy.shape)
+        p = ctx.saved_tensors[0]
+        dy2 = dy.reshape(p.shape).contiguous()
+        if ctx.listed:
+            return _native.entmax15_bwd_lists(dy2, p, ctx.saved_tensors[1], ctx.saved_tensors[2]).view(dy.shape)
+        return _native.entmax15_bwd(dy2, p).view(dy.shape)
 
 
 class _SparsemaxEntropy(torch.autograd.Function):

@@ -44,6 +44,44 @@ def test_fwd_bwd_match_oracle(dev, oracle_mod, R, K, sigma):
     assert np.abs(dx - dx_ref).max() <= 2e-5 * max(1.0, np.abs(dx_ref).max())
 
 
+@pytest.mark.parametrize("R,K,sigma,cap", [(40, 513, 1.0, 64), (17, 1000, 1.0, 64), (12, 2048, 1.0, 64),
+                                           (20, 4096, 1.0, 64), (33, 4096, 3.0, 8), (50, 4096, 0.3, 64),
+                                           (9, 3001, 1.0, 32), (25, 4096, 0.05, 64), (300, 1024, 2.0, 16)])
+def test_list_pair_matches_the_plain_pair(dev, oracle_mod, R, K, sigma, cap):
+    """smlvm_entmax15_fwd_lists / _bwd_lists (512 < K <= 4096): same p as the plain forward bit for
+    bit; a row's list names exactly its non-zeros, with sqrt(p) = z - tau beside them, or is marked
+    -2 (more non-zeros than slots, or a wide row that finished without candidates); the list
+    backward equals the p-based one and the oracle (2e-5 relative), rows without a list included."""
+    from lvmhelpers import _native
+    x = _rows(R, K, sigma, R * 7 + K)
+    xt = torch.from_numpy(x).to(dev)
+    p0, _, _ = _native.entmax15_fwd(xt)
+    p, cols, vals = _native.entmax15_fwd_lists(xt, cap=cap)
+    assert torch.equal(p, p0)
+    pn, c, v = p.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+    listed = 0
+    for r in range(R):
+        nz = np.flatnonzero(pn[r] > 0)
+        if c[r, 0] == -2:
+            continue
+        assert nz.size <= cap
+        assert sorted(c[r, :nz.size].tolist()) == nz.tolist(), (r, nz.size)
+        assert np.all(c[r, nz.size:] == -1)
+        assert np.abs(v[r, :nz.size] ** 2 - pn[r, c[r, :nz.size]]).max() <= 1e-6
+        listed += 1
+    if sigma >= 1.0 and cap == 64:
+        assert listed >= R - 2          # (rows 0 / 2 of _rows are all-equal / tie-ridden: wide supports)
+    dy = np.random.default_rng(K).standard_normal(x.shape).astype(np.float32)
+    dyt = torch.from_numpy(dy).to(dev)
+    dx = _native.entmax15_bwd_lists(dyt, p, cols, vals).cpu().numpy()
+    dx0 = _native.entmax15_bwd(dyt, p).cpu().numpy()
+    dx_ref = oracle_mod.entmax15_bwd(dy, pn)
+    top = max(1.0, np.abs(dx_ref).max())
+    assert np.abs(dx - dx_ref).max() <= 2e-5 * top
+    assert np.abs(dx - dx0).max() <= 2e-5 * top
+    assert np.array_equal(dx != 0, (pn > 0) & (dx != 0))     # nothing outside the support
+
+
 @pytest.mark.parametrize("K,sigma", [(10, 1.0), (256, 1.0), (256, 3.0)])
 def test_support_against_the_oracle_on_a_million_rows(dev, oracle_mod, K, sigma):
     """How many support elements differ from the oracle's (entmax15 is ExplicitWrapper's default
