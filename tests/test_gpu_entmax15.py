@@ -122,6 +122,17 @@ def test_autograd_and_module_paths(dev, oracle_mod):
         dref = oracle_mod.entmax15_bwd(np.moveaxis(w.cpu().numpy(), dim, -1).reshape(p_ref.shape), p_ref)
         got = np.moveaxis(xt.grad.cpu().numpy(), dim, -1).reshape(p_ref.shape)
         assert np.abs(got - dref).max() <= 3e-5
+    # rows of one wave (512 < K <= 4096) go through the list pair
+    for shape in ((3, 5, 1000), (7, 4096)):
+        xw = rng.standard_normal(shape).astype(np.float32)
+        xt = torch.from_numpy(xw).to(dev).requires_grad_(True)
+        p = F_.entmax15(xt, dim=-1)
+        w = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).to(dev)
+        (p * w).sum().backward()
+        p_ref, _, _ = oracle_mod.entmax15_fwd(xw.reshape(-1, shape[-1]))
+        assert np.abs(p.detach().cpu().numpy().reshape(p_ref.shape) - p_ref).max() <= 2e-6
+        dref = oracle_mod.entmax15_bwd(w.cpu().numpy().reshape(p_ref.shape), p_ref)
+        assert np.abs(xt.grad.cpu().numpy().reshape(p_ref.shape) - dref).max() <= 3e-5
     assert entmax.entmax15 is F_.entmax15
     x2 = rng.standard_normal((64, 10)).astype(np.float32)
     t = rng.integers(0, 10, 64)
