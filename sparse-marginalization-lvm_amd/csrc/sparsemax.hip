@@ -970,24 +970,33 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                             if (solved) break;
                         }
                     }
-                    float v[NW];
+                    // (ONE wave runs it and hands the bound over through LDS: run by all NW waves
+                    // -- four to a SIMD, ~1000 instructions each for a narrow row -- it was what a
+                    // narrow K = 65536 row paid over a plain one: 3.93 -> see DESIGN 3.1)
+                    float* bound_slot = lmx + NW * 64;
+                    if (wave == 0) {
+                        float v[NW];
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) v[w] = lmx[w * 64 + lane];
-                    tau = -1.0f;
-                    for (int cp = 0x7fffffff;;) {
-                        int cn = 0;
-                        float sm = 0.0f;
+                        for (int w = 0; w < NW; ++w) v[w] = lmx[w * 64 + lane];
+                        tau = -1.0f;
+                        for (int cp = 0x7fffffff;;) {
+                            int cn = 0;
+                            float sm = 0.0f;
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) {
-                            const bool in = v[w] > tau;
-                            cn += in ? 1 : 0;
-                            sm += in ? v[w] : 0.0f;
+                            for (int w = 0; w < NW; ++w) {
+                                const bool in = v[w] > tau;
+                                cn += in ? 1 : 0;
+                                sm += in ? v[w] : 0.0f;
+                            }
+                            wred.cs(cn, sm);
+                            if (cn >= cp) break;
+                            cp = cn;
+                            tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
                         }
-                        wred.cs(cn, sm);
-                        if (cn >= cp) break;
-                        cp = cn;
-                        tau = fmaxf(tau, (sm - 1.0f) / (float)cn);
+                        if (lane == 0) *bound_slot = tau;
                     }
+                    __syncthreads();
+                    tau = *bound_slot;
                     thr = fmaxf(tau - margin, floor_k);
                     continue;
                 }
@@ -1844,7 +1853,7 @@ __global__ __launch_bounds__(64 * NW, 4) void sparsemax_fwd_block_kernel(
     int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    __shared__ float cand[3 * NW * 64 + NW];   // candidate values, counts, columns, lane maxima
+    __shared__ float cand[3 * NW * 64 + NW + 4];   // candidate values, counts, columns, lane maxima, subset bound
     // XCD-aware row order for the small workgroups (K = 16384 forward 1.45 -> 1.37 ms; neutral at
     // NW = 8, a loss at NW = 16 where one workgroup fills the CU)
     for (int64_t row0 = xcd_block<(NW <= 4)>(); row0 < R; row0 += gridDim.x) {
