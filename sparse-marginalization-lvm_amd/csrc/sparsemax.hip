@@ -863,7 +863,7 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                     worst = k > worst ? k : worst;
                 }
                 fast = worst <= 64 && total <= kCandCap;
-                if (fast) {
+                if (fast && wave == 0) {   // (wave 0 solves for the workgroup, below)
 #pragma unroll
                     for (int q = 0; q < kCandPerLane; ++q) {
                         const int idx = lane + 64 * q;
@@ -1022,19 +1022,47 @@ __device__ __forceinline__ bool sparsemax_row(float (&z)[E], Red& red, float* ca
                 thr = fmaxf(tau - margin, floor_k);
             }
         }
-        if (fast && !solved) {
-            WaveRed<64> wred;  // every wave solves the same small problem: no barriers
-            int m_robust = 0;
-            solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
-            // a list cut above the floor must be shown to hold everything the oracle could count
-            if (thr_used > floor_k && !lazy_list_is_complete(thr_used, tau_used, m_robust, K)) fast = false;
-        }
-        if (fast) {
-            if (list) {   // NW > 1: every wave holds the same candidates, wave 0 writes
-                const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
-                n_listed = emit_cols_from_candidates<kCandPerLane, 64>(
-                    c, cc, tau_c, lane, 0, list, cap, live && (NW == 1 || threadIdx.x < 64), mark, vdelta);
+        if constexpr (NW == 1) {
+            if (fast && !solved) {
+                WaveRed<64> wred;
+                int m_robust = 0;
+                solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
+                // a list cut above the floor must be shown to hold everything the oracle could count
+                if (thr_used > floor_k && !lazy_list_is_complete(thr_used, tau_used, m_robust, K)) fast = false;
             }
+            if (fast && list) {
+                const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+                n_listed = emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap, live, mark, vdelta);
+            }
+        } else if (fast) {   // (workgroup-uniform: decided on the counts in LDS)
+            // Wave 0 searches the candidates for the whole workgroup and leaves the result in LDS;
+            // the other waves wait at one barrier.  (Every wave used to hold the candidates and run
+            // the same search on them -- no barrier, but four waves to a SIMD: the CU spent four
+            // times the search on it while its loads were done and its stores not yet started.)
+            float* res = cand + 3 * NW * 64 + NW + 1;   // s, S lo, S hi, still-fast flag
+            if (wave_index() == 0) {
+                bool ok = true;
+                if (!solved) {
+                    WaveRed<64> wred;
+                    int m_robust = 0;
+                    solve_core(c, wred, kCandCap, s_final, S_final, &m_robust);
+                    if (thr_used > floor_k && !lazy_list_is_complete(thr_used, tau_used, m_robust, K)) ok = false;
+                }
+                if (ok && list) {
+                    const float tau_c = ((float)S_final - 1.0f) / (float)s_final;
+                    n_listed = emit_cols_from_candidates<kCandPerLane, 64>(c, cc, tau_c, lane, 0, list, cap, live, mark, vdelta);
+                }
+                if (lane == 0) {
+                    res[0] = __int_as_float(s_final);
+                    res[1] = __int_as_float(__double2loint(S_final));
+                    res[2] = __int_as_float(__double2hiint(S_final));
+                    res[3] = ok ? 1.0f : 0.0f;
+                }
+            }
+            __syncthreads();
+            s_final = __float_as_int(res[0]);
+            S_final = __hiloint2double(__float_as_int(res[2]), __float_as_int(res[1]));
+            fast = res[3] != 0.0f;
         }
     }
     if (__builtin_expect(!fast && !solved, 0)) solve_core(z, red, K, s_final, S_final, nullptr, full_tau, full_fixed);
@@ -1853,7 +1881,7 @@ __global__ __launch_bounds__(64 * NW, 4) void sparsemax_fwd_block_kernel(
     int32_t* __restrict__ cols, int cap, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    __shared__ float cand[3 * NW * 64 + NW + 4];   // candidate values, counts, columns, lane maxima, subset bound
+    __shared__ float cand[3 * NW * 64 + NW + 8];   // candidate values, counts, columns, lane maxima, subset bound, wave 0's result
     // XCD-aware row order for the small workgroups (K = 16384 forward 1.45 -> 1.37 ms; neutral at
     // NW = 8, a loss at NW = 16 where one workgroup fills the CU)
     for (int64_t row0 = xcd_block<(NW <= 4)>(); row0 < R; row0 += gridDim.x) {
