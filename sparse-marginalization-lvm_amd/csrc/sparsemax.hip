@@ -2764,7 +2764,7 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
                         worst = k > worst ? k : worst;
                     }
                     listed = worst <= 64 && total <= kCandCap;   // (a wave's list holds 64)
-                    if (listed) {
+                    if (listed && wave == 0) {
 #pragma unroll
                         for (int q = 0; q < kCandPerLane; ++q) {
                             const int idx = lane + 64 * q;
@@ -2788,14 +2788,24 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
     }
     if constexpr (NW >= 1) {
         if (listed) {
-            WaveRed<64> wred;   // every wave solves the same small problem: no barriers
-            for (; it < kE15MaxNewton; ++it) {
-                float cnt;
-                const float step = entmax15_newton_step(c, tau, wred, cnt);
-                if (!(step > 1e-7f)) break;
-                tau += step;
+            // one wave iterates on the list (NW > 1: for the workgroup, which waits at one barrier;
+            // run by every wave it cost a CU -- four waves to a SIMD -- four times the iteration)
+            if (NW == 1 || wave_index() == 0) {
+                WaveRed<64> wred;
+                for (; it < kE15MaxNewton; ++it) {
+                    float cnt;
+                    const float step = entmax15_newton_step(c, tau, wred, cnt);
+                    if (!(step > 1e-7f)) break;
+                    tau += step;
+                }
+                tau = entmax15_closed_form(c, tau, wred);
             }
-            tau = entmax15_closed_form(c, tau, wred);
+            if constexpr (NW > 1) {
+                float* slot = cand + NW * 64 + NW;
+                if (threadIdx.x == 0) *slot = tau;
+                __syncthreads();
+                tau = *slot;
+            }
         }
     }
     if (!listed) tau = entmax15_closed_form(z, tau, red);
@@ -2872,7 +2882,7 @@ __global__ __launch_bounds__(64 * NW, 4) void entmax15_fwd_block_kernel(
     float* __restrict__ tau, int64_t R, int K)
 {
     __shared__ unsigned long long lds[BlockRed<NW>::kLdsWords];
-    __shared__ float cand[NW * 64 + NW];
+    __shared__ float cand[NW * 64 + NW + 4];   // per-wave lists, counts, wave 0's tau
     for (int64_t row0 = blockIdx.x; row0 < R; row0 += gridDim.x) {
         const int64_t row = rot8(row0, R);
         float z[E];
