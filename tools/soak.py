@@ -1,7 +1,7 @@
 """GPU box: randomized parity soak with FRESH seeds (the test suite's seeds are fixed): sparsemax
 forward (p, supp bit-exact), list backward (against the p-based backward and the oracle), the
 compaction lists, the SparseMAP solver and the sequence factor (everything identical to the oracle).
-    python tools/soak.py [seconds] [seed] [other]     (other: k-best bit vectors and entmax15 instead)
+    python tools/soak.py [seconds] [seed] [other]     (other: k-best bit vectors, entmax15 and its\n                                                       list pair, compaction of any matrix, entropy,\n                                                       scatter and the decoder loss instead)
 Prints one line per 50 trials and every mismatch with what reproduces it; exit status 1 on any."""
 import sys
 import time
@@ -171,6 +171,102 @@ def entmax15_trial(rng, trial):
         bad += 1
         print(f"MISMATCH entmax15: trial {trial} R {R} K {K} kind/sigma {tag} p err {e_p:.2e} dx err {e_dx:.2e}",
               flush=True)
+        return
+    if not _native.entmax15_has_lists(K):
+        return
+    # the list pair: p bit for bit, a list names exactly the row's non-zeros (or -2), same dx
+    cap = int(rng.choice([1, 3, 8, 16, 32, 64]))
+    xt = torch.from_numpy(x).to(dev)
+    p2, cols, vals = _native.entmax15_fwd_lists(xt, cap=cap)
+    pn, c, v = p2.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+    ok = torch.equal(p2, p)
+    for r in range(R):
+        if not ok or c[r, 0] == -2:
+            continue
+        nz = np.flatnonzero(pn[r] > 0)
+        ok = (nz.size <= cap and sorted(c[r, :nz.size].tolist()) == nz.tolist() and np.all(c[r, nz.size:] == -1)
+              and np.abs(v[r, :nz.size] ** 2 - pn[r, c[r, :nz.size]]).max() <= 1e-6)
+    dx2 = _native.entmax15_bwd_lists(torch.from_numpy(dy).to(dev), p2, cols, vals).cpu().numpy()
+    e_dx2 = np.abs(dx2 - dx_ref).max() / max(1e-30, np.abs(dy).max())
+    if not (ok and e_dx2 <= 2e-5 and np.all((dx2 == 0) | (pn > 0))):
+        bad += 1
+        print(f"MISMATCH entmax15 lists: trial {trial} R {R} K {K} cap {cap} kind/sigma {tag} lists ok {ok} "
+              f"dx err {e_dx2:.2e}", flush=True)
+
+
+def compaction_trial(rng, trial):
+    """Any non-negative matrix (not only a sparsemax output): fused single-pass compaction, the
+    separate launches, the entropy reduction and the scatter against the oracle / numpy."""
+    global bad
+    K = int(rng.choice([rng.integers(1, 65), rng.integers(65, 257), rng.integers(257, 1100),
+                        rng.choice([8, 10, 32, 64, 128, 256, 512, 1024, 4096])]))
+    R = int(rng.integers(1, max(2, min(20000, (1 << 22) // K))))
+    dens = float(rng.choice([0.0, 0.002, 0.03, 0.2, 0.7, 1.0]))
+    pm = rng.random((R, K)).astype(np.float32)
+    pm[rng.random((R, K)) >= dens] = 0.0
+    if rng.random() < 0.3:
+        pm[rng.random(R) < 0.5] = 0.0                 # whole empty rows
+    off_ref, r_ref, c_ref, v_ref = oracle.support_compact(pm)
+    pt = torch.from_numpy(pm).to(dev)
+    res = {"fused": _native.support_compact_fused(pt, want_vals=True),
+           "split": _native.support_compact(pt, want_vals=True, fused=False)}
+    for name, out in res.items():
+        if out is None:
+            continue
+        off, rws, cls, vals = out[:4]
+        if not (np.array_equal(off.cpu().numpy(), off_ref) and np.array_equal(rws.cpu().numpy(), r_ref)
+                and np.array_equal(cls.cpu().numpy(), c_ref) and np.array_equal(vals.cpu().numpy(), v_ref)):
+            bad += 1
+            print(f"MISMATCH compaction {name}: trial {trial} R {R} K {K} density {dens}", flush=True)
+            return
+    vt = torch.from_numpy(v_ref).to(dev)
+    inv_b = 1.0 / R
+    ent = float(_native.support_entropy_fwd(vt, inv_b)[0])
+    v64 = v_ref.astype(np.float64)
+    ent_ref = -inv_b * float((v64 * np.log(v64)).sum()) if v_ref.size else 0.0
+    if not abs(ent - ent_ref) <= 2e-6 * max(1.0, abs(ent_ref)):
+        bad += 1
+        print(f"MISMATCH entropy: trial {trial} N {v_ref.size} got {ent!r} want {ent_ref!r}", flush=True)
+    g = rng.standard_normal(v_ref.size).astype(np.float32)
+    dense = _native.support_scatter(torch.from_numpy(g).to(dev), torch.from_numpy(off_ref).to(dev),
+                                    torch.from_numpy(c_ref).to(dev), R, K).cpu().numpy()
+    want = np.zeros((R, K), np.float32)
+    want[r_ref, c_ref] = g
+    if not np.array_equal(dense, want):
+        bad += 1
+        print(f"MISMATCH scatter: trial {trial} R {R} K {K} density {dens}", flush=True)
+
+
+def lowrank_trial(rng, trial):
+    """decoder loss: loss / lse against fp64, dxdir against the fp64 gradient (1e-5 of its scale)"""
+    global bad
+    N, F_ = int(rng.integers(1, 40)), int(rng.integers(1, 900))
+    C, Rk = int(rng.choice([2, 10, 100, 256])), int(rng.choice([1, 2, 3, 4, 5, 8]))
+    sc = float(rng.choice([0.1, 1.0, 3.0, 10.0]))
+    x = (sc * rng.standard_normal((N, F_, Rk))).astype(np.float32)
+    w = rng.standard_normal((C, Rk)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    y = rng.integers(0, C, (N, F_))
+    try:
+        out = _native.lowrank_ce_fwd(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev),
+                                     torch.from_numpy(b).to(dev), torch.from_numpy(y).to(dev), want_dxdir=True)
+    except _native.NativeError:
+        return                                        # a rank the kernels are not built for
+    loss, lse, dxd = out[0].cpu().numpy(), out[1].cpu().numpy(), out[3].cpu().numpy()
+    lg = x.astype(np.float64) @ w.astype(np.float64).T + b
+    m = lg.max(-1, keepdims=True)
+    lse_ref = (m + np.log(np.exp(lg - m).sum(-1, keepdims=True)))[..., 0]
+    sm = np.exp(lg - lse_ref[..., None])
+    nll = lse_ref - np.take_along_axis(lg, y[..., None], -1)[..., 0]
+    sm[np.arange(N)[:, None], np.arange(F_)[None, :], y] -= 1.0
+    dxd_ref = sm @ w.astype(np.float64)
+    e1 = np.abs(lse - lse_ref).max() / max(1.0, np.abs(lse_ref).max())
+    e2 = np.abs(loss - nll.sum(1)).max() / max(1.0, np.abs(nll.sum(1)).max())
+    e3 = np.abs(dxd - dxd_ref).max() / max(1.0, np.abs(dxd_ref).max())
+    if not (e1 <= 2e-6 and e2 <= 5e-6 and e3 <= 1e-5):
+        bad += 1
+        print(f"MISMATCH lowrank ce: trial {trial} N {N} F {F_} C {C} R {Rk} scale {sc} "
+              f"lse {e1:.2e} loss {e2:.2e} dxdir {e3:.2e}", flush=True)
 
 
 only = sys.argv[3] if len(sys.argv) > 3 else ""
@@ -179,7 +275,7 @@ trial = 0
 while time.time() - t0 < budget_s:
     rng = np.random.default_rng([seed0, trial])
     if only == "other":
-        (topk_trial if trial % 2 else entmax15_trial)(rng, trial)
+        (topk_trial, entmax15_trial, compaction_trial, entmax15_trial, lowrank_trial)[trial % 5](rng, trial)
     elif trial % 3 == 2:
         sparsemap_trial(rng, trial)
     else:
