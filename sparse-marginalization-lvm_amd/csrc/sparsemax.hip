@@ -38,6 +38,7 @@ __device__ __forceinline__ float uniform(float v)
 // the per-element compare masks from having to stay alive (in SGPRs) from one pass to the next.
 template <int G>
 struct WaveRed {
+    static constexpr int kLanes = G;
     // position of this lane among the lanes that hold the row, and how many there are
     __device__ __forceinline__ int idx() const { return (int)(threadIdx.x & 63) % G; }
     __device__ __forceinline__ int stride() const { return G; }
@@ -2665,8 +2666,12 @@ __device__ __forceinline__ float entmax15_newton_step(const float (&v)[N], float
     }
     double a = (double)s1, b = (double)s2;
     red.sum2(a, b);
-    lower = (float)a * (float)a / (float)b;
-    return (float)((b - 1.0) / (2.0 * a));
+    // b - 1 cancels and is taken in fp64; the quotients need no more than v_rcp_f32 gives (the
+    // partial sums carry fp32 rounding already; an fp64 division per step was a fifth of the
+    // lane-group kernels' iteration)
+    const float af = (float)a;
+    lower = af * af * __builtin_amdgcn_rcpf((float)b);
+    return (float)(b - 1.0) * __builtin_amdgcn_rcpf(2.0f * af);
 }
 
 // the package's closed form on the set {v > tau}: tau = mean - sqrt((1 - ss)/c), fp64
@@ -2693,8 +2698,9 @@ __device__ __forceinline__ float entmax15_closed_form(const float (&v)[N], float
     return tau;
 }
 
-// NW = waves that hold the row (0: a lane group of one wave, no candidate lists).
-// cand: LDS, NW == 1: kCandCap floats private to the wave; NW > 1: NW*64 floats + NW ints.
+// NW = waves that hold the row (0: a lane group of one wave; GC: with candidate lists per group).
+// cand: LDS, NW == 1: kCandCap floats private to the wave; NW > 1: NW*64 floats + NW ints;
+// NW == 0 with GC: kCandCap floats private to the wave, a slice of 4 G per lane group.
 //
 // Candidates (round 3).  The Newton iterates rise monotonically and never pass the root, so every
 // set {z > tau_k} holds the support and the iteration from tau_k on only ever looks at that set.
@@ -2706,7 +2712,7 @@ __device__ __forceinline__ float entmax15_closed_form(const float (&v)[N], float
 // list != nullptr (NW == 1 only): the row's support list -- columns with p > 0, and at byte distance
 // vdelta the values sqrt(p) = z - tau slot for slot (what the backward weighs with) -- comes from the
 // candidates; rows that finished full width are marked kColsOverflow (their backward reads p).
-template <int E, int NW, bool VEC, class Red>
+template <int E, int NW, bool VEC, bool GC = false, class Red>
 __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_out, float& tau_out,
                                              float* cand = nullptr, int32_t* list = nullptr, int cap = 0,
                                              bool live = true, long long vdelta = 0)
@@ -2733,6 +2739,42 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
         const bool moving = step > 1e-7f;            // false for NaN rows too
         if (moving) tau += step;
         if (__ballot(moving) == 0ull) break;         // every row this wave holds has converged
+        if constexpr (NW == 0 && GC) {
+            // Several rows per wave: every lane group compacts its row's set into its slice of the
+            // wave's list once EVERY row's bound says it may fit (the decision is the wave's: the
+            // rows run one instruction stream), and the remaining steps look at 4 values per lane.
+            constexpr int G = Red::kLanes, CAP = G * kCandPerLane;
+            static_assert((64 / G) * CAP <= kCandCap, "the wave's slice holds every group's list");
+            if (__ballot(cnt > try_below * ((float)CAP / (float)kCandCap)) == 0ull) {
+                const int lane = threadIdx.x & 63, gl = lane % G;
+                float* clist = cand + (lane / G) * CAP;
+                int mine = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) mine += z[e] > tau ? 1 : 0;
+                const int incl = group_scan_incl<G>(mine, gl);
+                if (__ballot(incl > CAP) == 0ull) {  // (incl of a group's last lane is its total)
+                    const int total = __shfl(incl, lane | (G - 1));
+                    int off = incl - mine;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const bool in = z[e] > tau;
+                        if (__ballot(in) != 0ull) {  // wave-uniform
+                            if (in) clist[off] = z[e];
+                            off += in ? 1 : 0;
+                        }
+                    }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int q = 0; q < kCandPerLane; ++q)
+                        c[q] = (gl + G * q < total) ? clist[gl + G * q] : -INFINITY;
+                    wave_lds_sync();
+                    listed = true;
+                    ++it;
+                    break;
+                }
+                try_below *= 0.5f;
+            }
+        }
         if constexpr (NW >= 1) {
             // cnt bounds {z > tau_k} BEFORE the step; the set above the new tau is a subset
             if (cnt <= try_below) {                  // wave- (NW == 1) / workgroup-uniform
@@ -2808,6 +2850,18 @@ __device__ __forceinline__ void entmax15_row(float (&z)[E], Red& red, int& nnz_o
             }
         }
     }
+    if constexpr (NW == 0 && GC) {
+        if (listed) {
+            for (; it < kE15MaxNewton; ++it) {
+                float cnt;
+                const float step = entmax15_newton_step(c, tau, red, cnt);
+                const bool moving = step > 1e-7f;
+                if (moving) tau += step;
+                if (__ballot(moving) == 0ull) break;
+            }
+            tau = entmax15_closed_form(c, tau, red);
+        }
+    }
     if (!listed) tau = entmax15_closed_form(z, tau, red);
     if constexpr (NW == 1) {
         if (list) {
@@ -2861,10 +2915,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, E <= 32 ? 5 : 4) void entmax15
     int n;
     float t;
     constexpr bool CAND = (G == 64);   // one row per wave: a candidate list (values, columns) per wave
-    __shared__ float cand[CAND ? kWavesPerBlock * 2 * kCandCap : 1];
+    constexpr bool GCAND = (G < 64) && (E >= 8);   // several rows per wave: a list of values per lane group
+    __shared__ float cand[CAND ? kWavesPerBlock * 2 * kCandCap : GCAND ? kWavesPerBlock * kCandCap : 1];
     if constexpr (CAND)
         entmax15_row<E, 1, VEC>(z, red, n, t, cand + (threadIdx.x >> 6) * 2 * kCandCap,
                                 cols ? cols + row * cap : nullptr, cap, live, vdelta);
+    else if constexpr (GCAND)
+        entmax15_row<E, 0, VEC, true>(z, red, n, t, cand + (threadIdx.x >> 6) * kCandCap);
     else
         entmax15_row<E, 0, VEC>(z, red, n, t);
     if (live) {
