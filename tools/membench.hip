@@ -253,6 +253,52 @@ __global__ __launch_bounds__(1024) void k_copy_wg(const float4* __restrict__ a, 
     }
 }
 
+// Two passes over a tile of TILE_KB per workgroup of BS threads, several workgroups per CU (round 3
+// probe for rows too wide for one wave): pass 1 streams the tile with ordinary loads (maximum of the
+// tile, `work` rounds of dependent VALU work in one wave stand in for the threshold search), pass 2
+// reads it again -- from the L2 / the memory-side cache if it is still there -- and stores it.
+template <int BS>
+__global__ __launch_bounds__(BS) void k_two_pass(const float4* __restrict__ a, float4* __restrict__ o,
+                                                  size_t ntiles, int f4_per_tile, int work)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[BS / 64];
+    const f4* s4 = reinterpret_cast<const f4*>(a);
+    f4* d4 = reinterpret_cast<f4*>(o);
+    for (size_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const f4* src = s4 + t * f4_per_tile;
+        float m = -1e30f;
+        for (int i = threadIdx.x; i < f4_per_tile; i += BS * 8) {
+            f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + u * BS < f4_per_tile) ? src[i + u * BS] : f4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(fmaxf(fmaxf(m, v[u].x), fmaxf(v[u].y, v[u].z)), v[u].w);
+        }
+        for (int d = 32; d; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float r = threadIdx.x < BS / 64 ? red[threadIdx.x] : -1e30f;
+            for (int d = 32; d; d >>= 1) r = fmaxf(r, __shfl_xor(r, d));
+            r = burn(r, work);
+            if (threadIdx.x == 0) red[0] = r;
+        }
+        __syncthreads();
+        const float tau = red[0];
+        f4* dst = d4 + t * f4_per_tile;
+        for (int i = threadIdx.x; i < f4_per_tile; i += BS * 8) {
+            f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (i + u * BS < f4_per_tile) ? __builtin_nontemporal_load(src + i + u * BS) : f4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i + u * BS < f4_per_tile) __builtin_nontemporal_store(v[u] - tau, dst + i + u * BS);
+        }
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv)
 {
     size_t bytes = (size_t)16 << 30;  // per tensor
@@ -262,6 +308,18 @@ int main(int argc, char** argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, bytes));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 1, bytes));
     double t;
+    if (argc > 6) {
+        for (int kb : {256, 64, 32}) {
+            const int f4t = kb * 64;
+            const size_t nt = n / f4t;
+            for (int work : {0, 300}) {
+#define TP(BS, G) t = timeit([&] { k_two_pass<BS><<<G, BS>>>(a, o, nt, f4t, work); }); \
+    printf("two-pass %d KB tiles work=%d BS=%d grid=%d: %.2f TB/s (on 2 x bytes)\n", kb, work, BS, G, 2.0 * bytes / t / 1e12);
+                TP(1024, 256) TP(1024, 512) TP(512, 512) TP(512, 1024) TP(256, 1024) TP(256, 2048)
+            }
+        }
+        return 0;
+    }
     if (argc > 5) {
         const size_t nt = n / 16384;
         CK(hipFuncSetAttribute((const void*)k_copy_wg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
