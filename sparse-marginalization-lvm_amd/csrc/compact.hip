@@ -1025,6 +1025,26 @@ static int support_count_go(const float* p, const int32_t* lists, int32_t cap, i
     return check_launch();
 }
 
+// Zeroes `n` 8-byte words.  A kernel, not hipMemsetAsync: inside a stream capture the memset becomes
+// a graph node of its own, and in replays of such a graph (ROCm 7.2, lvmhelpers/graphs.py) it was
+// seen to run ahead of kernel nodes captured before it -- an earlier kernel's temporary, placed at
+// the same address by the allocator, then overwrote the zeroed ticket counter and the fused
+// compaction returned without writing its offsets.  A kernel node keeps its place in the chain.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* __restrict__ w, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) w[i] = 0ull;
+}
+
+static int zero_words(void* dst, size_t bytes, hipStream_t st)
+{
+    const long long n = (long long)(bytes / sizeof(unsigned long long));
+    if (n == 0) return SMLVM_OK;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    if (grid > 64u) grid = 64u;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, st, static_cast<unsigned long long*>(dst), n);
+    return SMLVM_OK;
+}
+
 extern "C" int smlvm_support_count(const float* p, int32_t* nnz, int64_t R, int32_t K, void* stream)
 {
     return support_count_go(p, nullptr, 0, nnz, R, K, stream);
@@ -1048,7 +1068,7 @@ extern "C" int smlvm_support_offsets(const int32_t* nnz, int64_t* row_offsets, i
     if (R < 0 || !row_offsets) return SMLVM_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (R == 0) {
-        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        zero_words(row_offsets, sizeof(int64_t), st);
         return SMLVM_OK;
     }
     if (!nnz) return SMLVM_ERR_INVALID;
@@ -1110,7 +1130,7 @@ extern "C" int smlvm_support_offsets_noalloc(const int32_t* nnz, int64_t* row_of
     if (R > kNoAllocMaxRows) return SMLVM_ERR_UNSUPPORTED;   // beyond the static block-sum array
     hipStream_t st = (hipStream_t)stream;
     if (R == 0) {
-        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        zero_words(row_offsets, sizeof(int64_t), st);
         return SMLVM_OK;
     }
     if (!nnz) return SMLVM_ERR_INVALID;
@@ -1187,9 +1207,9 @@ extern "C" int smlvm_support_compact_fused(const float* p, const int32_t* suppor
     const size_t need = smlvm_support_compact_fused_workspace_bytes(R);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return SMLVM_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, need, st) != hipSuccess) return SMLVM_ERR_HIP;
+    zero_words(workspace, need, st);
     if (R == 0) {
-        if (hipMemsetAsync(row_offsets, 0, sizeof(int64_t), st) != hipSuccess) return SMLVM_ERR_HIP;
+        zero_words(row_offsets, sizeof(int64_t), st);
         return SMLVM_OK;
     }
     if (!p) return SMLVM_ERR_INVALID;

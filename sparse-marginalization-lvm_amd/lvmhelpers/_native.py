@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsparsemarg_hip.so")
 _lib = None
 
 ABI_SYMBOLS = [
-    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error",
+    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error", "smlvm_graph_memsets_to_kernels",
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy", "smlvm_entmax15_fwd", "smlvm_entmax15_bwd",
     "smlvm_entmax15_fwd_lists", "smlvm_entmax15_bwd_lists",
@@ -301,7 +301,7 @@ FUSED_SMALL = 1 << 22       # R * K up to which the bound is simply R * K
 
 
 def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=True, want_cols=True,
-                          want_vals=True, n_cap=None, host_offsets=False):
+                          want_vals=True, n_cap=None, host_offsets=False, static=False):
     """Count + offsets + compaction in ONE launch (smlvm_support_compact_fused) and one host sync
     (N).  The outputs are sized by an upper bound on N -- R * cap when the rows have lists, R * K
     for small matrices -- and returned as views of length N; should N exceed the bound (rows
@@ -309,7 +309,11 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     (row_offsets, rows, cols, vals) like support_compact, or None when no affordable bound exists.
     host_offsets=True appends the offsets as a host numpy array, read back in the SAME transfer as
     N (the callers that need per-row counts on the host -- SparseMAPWrapper's `support` / `idxs`
-    lists -- then pay one device-to-host copy per step instead of two)."""
+    lists -- then pay one device-to-host copy per step instead of two).
+    static=True: no host sync at all and shapes that do not depend on the data (what a step captured
+    in a HIP graph needs, lvmhelpers/graphs.py): the outputs keep their full length R * K, the
+    entries behind the N real ones are (row 0, col 0, val 0.0), and N stays on the device as
+    row_offsets[R]."""
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     dev = p.device
@@ -325,6 +329,10 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
         support_vals = _need_gpu(support_vals, torch.float32, "support_vals")
         if support_cols is None or tuple(support_vals.shape) != tuple(support_cols.shape):
             raise ValueError("support_vals must match support_cols")
+    if static:
+        if n_cap is not None and n_cap < R * K:
+            raise ValueError("static compaction: the outputs must hold R * K entries")
+        n_cap = R * K
     if n_cap is None:
         # small matrices: R * K can never overflow; with lists: twice the list capacity per row
         # (rows without a list -- more than cap non-zeros -- are paid for by the rows with short
@@ -338,14 +346,17 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     nbytes = lib().smlvm_support_compact_fused_workspace_bytes(_i64(R))
     both = torch.empty(nbytes // 8 + R + 1, dtype=torch.int64, device=dev)   # workspace | offsets
     ws, off = both[:nbytes // 8], both[nbytes // 8:]
-    rows = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_rows else None
-    cols = torch.empty(n_cap, dtype=torch.int32, device=dev) if want_cols else None
-    vals = torch.empty(n_cap, dtype=torch.float32, device=dev) if want_vals else None
+    alloc = torch.zeros if static else torch.empty
+    rows = alloc(n_cap, dtype=torch.int32, device=dev) if want_rows else None
+    cols = alloc(n_cap, dtype=torch.int32, device=dev) if want_cols else None
+    vals = alloc(n_cap, dtype=torch.float32, device=dev) if want_vals else None
     with torch.cuda.device(dev):
         _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
                                                  _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
                                                  _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
                                                  _stream()), "smlvm_support_compact_fused")
+    if static:
+        return off, rows, cols, vals
     if R == 0:
         return (off, rows, cols, vals) + ((off.cpu().numpy(),) if host_offsets else ())
     off_h = None
@@ -669,3 +680,13 @@ def segmented_logsumexp(v, row_offsets, shift=0.0):
         _check(lib().smlvm_segmented_logsumexp(_p(v), _p(row_offsets), _f32(float(shift)), _p(out),
                                                _i64(R), _stream()), "smlvm_segmented_logsumexp")
     return out
+
+
+# ----------------------------------------------------------------------------------- HIP graphs
+def graph_memsets_to_kernels(raw_graph):
+    """raw_graph: the hipGraph_t of a capture (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph())
+    -> (memset nodes found, replaced by kernel nodes); see include/sparsemarg.h."""
+    seen, done = ctypes.c_int32(0), ctypes.c_int32(0)
+    _check(lib().smlvm_graph_memsets_to_kernels(ctypes.c_void_p(int(raw_graph)), ctypes.byref(seen),
+                                                ctypes.byref(done)), "smlvm_graph_memsets_to_kernels")
+    return seen.value, done.value

@@ -66,6 +66,11 @@ class TopKSparsemaxMarg(torch.nn.Module):
         self.loss = loss_fun
         self.encoder_entropy_coeff = encoder_entropy_coeff
         self.decoder_entropy_coeff = decoder_entropy_coeff
+        # True: shapes that do not depend on the data and no host synchronisation -- all B * k
+        # (row, slot) pairs go through the decoder, the ones with p = 0 behind the real ones as
+        # (row 0, slot 0) with weight 0 -- so that a whole step can be captured in a HIP graph
+        # (lvmhelpers/graphs.py).  Same loss and gradients.
+        self.static_shapes = False
 
     def forward(self, encoder_input, decoder_input, labels):
         bit_vector_z, encoder_probs, encoder_entropy = self.encoder(encoder_input)
@@ -73,8 +78,12 @@ class TopKSparsemaxMarg(torch.nn.Module):
         entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
 
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
-        off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
-                                                        support_cols=F_.support_cols_of(encoder_probs))
+        if self.static_shapes:
+            off, rows, cols, vals = _native.support_compact_fused(
+                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True)
+        else:
+            off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
+                                                            support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         encoder_input_sel = encoder_input[rows_l]
         decoder_input_sel = decoder_input[rows_l]
@@ -116,6 +125,13 @@ class SparseMAPWrapper(nn.Module):
         self.init = init
         self.max_iter = max_iter
         self._idx_tensor = None
+        # True: `sample` / `distr` keep B * (n + 1) rows whatever the active sets hold (the rows
+        # behind the N real ones are sample 0's first configuration with probability 0), `idxs`
+        # and `support` are device tensors, and nothing is read back -- what a step captured in a
+        # HIP graph needs (lvmhelpers/graphs.py).  With init=True the initial scores live in one
+        # buffer that refresh_static() redraws (the same CPU draw as the eager path's, per step).
+        self.static_shapes = False
+        self._init_buffer = None
         # Data-parallel runs (opt-in): (rank, world, batch_total) of the shard this module sees, or
         # "auto" = ask torch.distributed (equal shards, same CPU seed on every rank -- the caller's
         # responsibility).  None (default) = the reference's draw: torch.rand(2n) per local sample
@@ -137,8 +153,35 @@ class SparseMAPWrapper(nn.Module):
             raise ValueError(f"SparseMAPWrapper.shard {shard} does not describe a batch of {batch_size}")
         return init_scores
 
+    def refresh_static(self):
+        """Redraws the static-shape mode's initial scores (one CPU draw per step, as in the eager
+        path); a captured step calls it before every replay."""
+        if self.init and self._init_buffer is not None:
+            b, n2 = self._init_buffer.shape
+            self._init_buffer.copy_(self._init_scores(b, n2 // 2, self._init_buffer.device))
+
+    def _forward_static(self, scores):
+        batch_size, latent_size = scores.shape
+        init_scores = None
+        if self.init:
+            if self._init_buffer is None or tuple(self._init_buffer.shape) != (batch_size, 2 * latent_size) \
+                    or self._init_buffer.device != scores.device:
+                self._init_buffer = self._init_scores(batch_size, latent_size, scores.device)
+            elif not torch.cuda.is_current_stream_capturing():
+                self.refresh_static()
+            init_scores = self._init_buffer
+        p, aset_bits, alen, _, _ = F_.sparsemap_batched(scores, init_scores, self.budget, self.max_iter)
+        off, rows, cols, vals = _native.support_compact_fused(p.detach(), static=True)
+        sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
+        distr = F_.gather_support(p, off, cols, vals)
+        self._idx_tensor = rows.long()
+        support = off[1:] - off[:-1]
+        return sample, distr, _support_entropy(distr, 1.0 / batch_size), self._idx_tensor, support
+
     def forward(self, *args, **kwargs):
         scores = self.agent(*args, **kwargs)
+        if self.static_shapes:
+            return self._forward_static(scores)
         batch_size, latent_size = scores.shape
         init_scores = None
         if self.init:
@@ -197,6 +240,10 @@ class SparseMAPMarg(torch.nn.Module):
         gather = getattr(self.encoder, '_idx_tensor', None)
         if gather is None or gather.numel() != len(idxs):
             gather = idxs
+        if torch.is_tensor(support):        # (static-shape mode: per-sample counts on the device)
+            support_log = support.to(torch.float)
+        else:
+            support_log = torch.tensor(support).to(torch.float)
 
         decoder_output = self.decoder(bit_vector_z)
         loss_components, logs = self.loss(
@@ -212,7 +259,7 @@ class SparseMAPMarg(torch.nn.Module):
                 logs[key] = v.mean()
         logs['loss'] = loss.detach()
         logs['encoder_entropy'] = encoder_entropy.detach()
-        logs['support'] = torch.tensor(support).to(torch.float)
+        logs['support'] = support_log
         logs['distr'] = encoder_probs.detach()
         logs['loss_output'] = loss_components.detach()
         logs['idxs'] = idxs
