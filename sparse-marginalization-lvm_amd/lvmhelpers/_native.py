@@ -311,9 +311,11 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     N (the callers that need per-row counts on the host -- SparseMAPWrapper's `support` / `idxs`
     lists -- then pay one device-to-host copy per step instead of two).
     static=True: no host sync at all and shapes that do not depend on the data (what a step captured
-    in a HIP graph needs, lvmhelpers/graphs.py): the outputs keep their full length R * K, the
-    entries behind the N real ones are (row 0, col 0, val 0.0), and N stays on the device as
-    row_offsets[R]."""
+    in a HIP graph needs, lvmhelpers/graphs.py): the outputs keep their full length n_cap (default
+    R * K, which cannot overflow), the entries behind the N real ones are (row 0, col 0, val 0.0),
+    and a fifth result, `n_total` [1] int64 on the device, is the true N.  With a smaller n_cap
+    the entries beyond it are dropped and the offsets are clipped to it (everything downstream
+    stays in bounds): n_total > n_cap says that this happened -- the caller's to check."""
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     dev = p.device
@@ -330,9 +332,7 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
         if support_cols is None or tuple(support_vals.shape) != tuple(support_cols.shape):
             raise ValueError("support_vals must match support_cols")
     if static:
-        if n_cap is not None and n_cap < R * K:
-            raise ValueError("static compaction: the outputs must hold R * K entries")
-        n_cap = R * K
+        n_cap = R * K if n_cap is None else max(1, min(int(n_cap), R * K))
     if n_cap is None:
         # small matrices: R * K can never overflow; with lists: twice the list capacity per row
         # (rows without a list -- more than cap non-zeros -- are paid for by the rows with short
@@ -356,7 +356,10 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
                                                  _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
                                                  _stream()), "smlvm_support_compact_fused")
     if static:
-        return off, rows, cols, vals
+        n_total = ws[2:3].clone()
+        if n_cap < R * K:
+            off.clamp_(max=n_cap)
+        return off, rows, cols, vals, n_total
     if R == 0:
         return (off, rows, cols, vals) + ((off.cpu().numpy(),) if host_offsets else ())
     off_h = None

@@ -17,6 +17,9 @@ which gives a capture its own pool.  The optimiser must keep its state on the de
     for batch in loader:
         out = step(*batch)          # {'loss': ..., 'log': {...}}: tensors that the next call overwrites
 
+`Marginalizer(compact=True)` has the same mode (all B * K pairs, or B * static_cap of them with an
+overflow flag that is checked every `check_every` steps).
+
 Limits: fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
 static-shape mode pays for B * k (top-k) or B * (n + 1) (SparseMAP) decoder rows instead of the
 support's, which is the right trade where a step is launch bound and the wrong one where the
@@ -57,7 +60,7 @@ class GraphedStep:
     generator back to where they were, so that creating a GraphedStep does not train.
     """
 
-    def __init__(self, model, optimizer, batch, warmup=3):
+    def __init__(self, model, optimizer, batch, warmup=3, check_every=50):
         if not all(torch.is_tensor(t) and t.is_cuda for t in batch):
             raise ValueError("GraphedStep: the batch must be a tuple of GPU tensors")
         for group in optimizer.param_groups:
@@ -65,6 +68,8 @@ class GraphedStep:
                 raise ValueError("GraphedStep: the optimiser must be created with capturable=True")
         self.model = model
         self.optimizer = optimizer
+        self.check_every = check_every
+        self._calls = 0
         self.static_batch = tuple(t.clone() for t in batch)
         self._switched = _set_static(model, True)
         self._refreshers = [m for m in model.modules() if hasattr(m, 'refresh_static')]
@@ -134,6 +139,11 @@ class GraphedStep:
         for m in self._refreshers:
             m.refresh_static()
         self.graph.replay()
+        self._calls += 1
+        flag = self.out['log'].get('support_overflow') if isinstance(self.out.get('log'), dict) else None
+        if flag is not None and self.check_every and self._calls % self.check_every == 0 and bool(flag):
+            raise RuntimeError("GraphedStep: a batch needed more (row, latent) pairs than static_cap "
+                               "leaves room for; raise Marginalizer.static_cap")
         return self.out
 
     def release(self):

@@ -102,12 +102,33 @@ class Marginalizer(torch.nn.Module):
             batch_dims = tuple(None if e.strip().lower() == "none" else int(e) for e in spec)
         self.batch_dims = batch_dims
         self.hoist = hoist
+        # compact mode only.  True: all B * K (row, latent) pairs go through the decoder, the ones
+        # with p = 0 behind the real ones as (row 0, latent 0) with weight 0; shapes then do not
+        # depend on the data and nothing is read back, so a whole step can be captured in a HIP
+        # graph (lvmhelpers/graphs.py).  Worth it for small K (the SSVAE's 10 classes) or a hoisted
+        # decoder whose per-pair part is cheap (the signal game's Receiver).
+        self.static_shapes = False
+        # static mode: room for this many (row, latent) pairs per row, B * static_cap in all, instead
+        # of K (None).  A batch whose supports need more loses the excess pairs -- the step's log
+        # then carries 'support_overflow' = True (a device tensor; GraphedStep looks at it every
+        # `check_every` steps and raises).  For large K with small supports: the signal game's 256
+        # symbols at a support of ~6.
+        self.static_cap = None
 
     def _forward_compact(self, encoder_input, decoder_input, labels, discrete_latent_z,
                          encoder_probs, encoder_entropy):
         batch_size, latent_size = encoder_probs.shape
-        off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
-                                                        support_cols=F_.support_cols_of(encoder_probs))
+        overflow = None
+        if self.static_shapes:
+            n_cap = None if self.static_cap is None else batch_size * min(latent_size, int(self.static_cap))
+            off, rows, cols, vals, n_total = _native.support_compact_fused(
+                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True,
+                n_cap=n_cap)
+            if n_cap is not None:
+                overflow = (n_total > n_cap).reshape(())
+        else:
+            off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
+                                                            support_cols=F_.support_cols_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         if rows_l.numel() == 0:
             raise RuntimeError("Marginalizer: the encoder distribution has no live category")
@@ -154,6 +175,8 @@ class Marginalizer(torch.nn.Module):
         logs['encoder_entropy'] = encoder_entropy.mean()
         logs['support'] = (encoder_probs != 0).sum(-1).to(torch.float).mean()
         logs['distr'] = encoder_probs
+        if overflow is not None:
+            logs['support_overflow'] = overflow
         return {'loss': loss_mean + entropy_loss.mean(), 'log': logs}
 
     def forward(self, encoder_input, decoder_input, labels):
@@ -162,6 +185,9 @@ class Marginalizer(torch.nn.Module):
         if self.compact:
             return self._forward_compact(encoder_input, decoder_input, labels, discrete_latent_z,
                                          encoder_probs, encoder_entropy)
+        if self.static_shapes:
+            raise RuntimeError("Marginalizer: static_shapes needs compact=True (the reference-order "
+                               "column loop reads the live columns back on the host)")
         entropy_loss = -(encoder_entropy.mean() * self.encoder_entropy_coeff)
 
         # columns whose probability mass is non-zero for some row (marg.py:87), one sync

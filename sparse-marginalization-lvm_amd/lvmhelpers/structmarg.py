@@ -79,7 +79,7 @@ class TopKSparsemaxMarg(torch.nn.Module):
 
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
         if self.static_shapes:
-            off, rows, cols, vals = _native.support_compact_fused(
+            off, rows, cols, vals, _ = _native.support_compact_fused(
                 encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True)
         else:
             off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
@@ -171,7 +171,7 @@ class SparseMAPWrapper(nn.Module):
                 self.refresh_static()
             init_scores = self._init_buffer
         p, aset_bits, alen, _, _ = F_.sparsemap_batched(scores, init_scores, self.budget, self.max_iter)
-        off, rows, cols, vals = _native.support_compact_fused(p.detach(), static=True)
+        off, rows, cols, vals, _ = _native.support_compact_fused(p.detach(), static=True)
         sample = _native.unpack_configs(aset_bits, rows, cols, latent_size)
         distr = F_.gather_support(p, off, cols, vals)
         self._idx_tensor = rows.long()

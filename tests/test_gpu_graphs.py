@@ -151,3 +151,74 @@ def test_captured_memsets_are_replaced_by_kernels(dev):
         torch.cuda.synchronize()
         assert float((box['y'] - (x * 2).sum(0)).abs().max()) <= 1e-3
         assert torch.equal(box['z'], (x * 2)[0, :1000])
+
+
+def _game(dev, batch, hoist, seed=0):
+    import bench_models
+    return bench_models.make_signal_game(dev, batch=batch, game_size=4, feat=64, vocab=32, seed=seed,
+                                         compact=True, hoist=hoist)
+
+
+@pytest.mark.parametrize("hoist", [False, True])
+def test_marginalizer_static_shapes_and_graph(dev, hoist):
+    """Marginalizer(compact=True).static_shapes: all B * K (row, latent) pairs, weight 0 outside the
+    support -- same loss, logs and gradients as the support-only lists; and the captured step
+    follows its eager twin."""
+    from lvmhelpers.graphs import GraphedStep
+    model, batch = _game(dev, 16, hoist)
+    ref = copy.deepcopy(model)
+    model.static_shapes = True
+    out_ref = ref(*batch)
+    out_ref['loss'].backward()
+    out = model(*batch)
+    out['loss'].backward()
+    assert torch.allclose(out['loss'], out_ref['loss'], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(out['log']['acc'], out_ref['log']['acc'], rtol=1e-5, atol=1e-6)
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-5 * max(1.0, float(q.grad.abs().max()))
+    # dense (reference-order) mode cannot be static
+    dense, b2 = _game(dev, 8, False)
+    dense.compact = False
+    dense.static_shapes = True
+    with pytest.raises(RuntimeError):
+        dense(*b2)
+    # captured step == eager static step, over changing batches
+    model, batch = _game(dev, 16, hoist, seed=1)
+    twin = copy.deepcopy(model)
+    twin.static_shapes = True
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2, momentum=0.9)
+    opt_twin = torch.optim.SGD(twin.parameters(), lr=1e-2, momentum=0.9)
+    step = GraphedStep(model, opt, batch)
+    for seed in range(3):
+        _, b = _game(dev, 16, hoist, seed=10 + seed)
+        out = step(*b)
+        opt_twin.zero_grad(set_to_none=True)
+        o2 = twin(*b)
+        o2['loss'].backward()
+        opt_twin.step()
+        assert abs(float(out['loss'].detach()) - float(o2['loss'].detach())) <= 1e-5 * max(1.0, abs(float(o2['loss'].detach())))
+    for p, q in zip(model.parameters(), twin.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-5 * max(1.0, float(q.detach().abs().max()))
+
+
+def test_static_cap_and_its_overflow_flag(dev):
+    """Marginalizer.static_cap: B * static_cap pairs instead of B * K; same loss while the supports
+    fit, and a batch that needs more says so in the log (and a GraphedStep raises when it looks)."""
+    from lvmhelpers.graphs import GraphedStep
+    model, batch = _game(dev, 16, True)
+    ref = copy.deepcopy(model)
+    model.static_shapes = True
+    with torch.no_grad():
+        support = int((ref(*batch)['log']['distr'] > 0).sum(-1).max())
+        model.static_cap = support
+        out = model(*batch)
+        assert not bool(out['log']['support_overflow'])
+        assert torch.allclose(out['loss'], ref(*batch)['loss'], rtol=1e-5, atol=1e-6)
+        model.static_cap = 1                      # a mean of one pair per row is not enough room
+        out = model(*batch)
+        assert bool(out['log']['support_overflow'])
+        assert bool(torch.isfinite(out['loss']))
+    step = GraphedStep(model, torch.optim.SGD(model.parameters(), lr=0.0), batch, check_every=2)
+    step(*batch)
+    with pytest.raises(RuntimeError):
+        step(*batch)
