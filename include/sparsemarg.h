@@ -327,8 +327,8 @@ int smlvm_segmented_logsumexp(const float* v, const int64_t* row_offsets, float 
 /* ---- HIP-graph repair pass (no counterpart in the reference; for lvmhelpers/graphs.py) ------------
  * Replaces every memset node of a captured hipGraph_t (child graphs included) by a kernel node that
  * writes the same bytes, with the same dependencies.  With the HIP runtime inside this image's
- * PyTorch wheel (7.0.51831) a captured memset takes effect on the first launch of the instantiated
- * graph only; PyTorch's own reductions (semaphores zeroed with cudaMemsetAsync) then return wrong
+ * PyTorch wheel (7.0.51831) a captured memset writes the captured value on the first launch of the
+ * instantiated graph only and an arbitrary word afterwards; PyTorch's own reductions (semaphores zeroed with cudaMemsetAsync) then return wrong
  * sums from the second replay on.  Call it on the graph BEFORE instantiating it.
  * n_memsets / n_replaced (may be NULL): memset nodes found / replaced.  SMLVM_ERR_UNSUPPORTED for
  * an element size other than 1, 2, 4; SMLVM_ERR_HIP when a graph API call fails (the graph may

@@ -1026,10 +1026,10 @@ static int support_count_go(const float* p, const int32_t* lists, int32_t cap, i
 }
 
 // Zeroes `n` 8-byte words.  A kernel, not hipMemsetAsync: inside a stream capture the memset becomes
-// a graph node of its own, and in replays of such a graph (ROCm 7.2, lvmhelpers/graphs.py) it was
-// seen to run ahead of kernel nodes captured before it -- an earlier kernel's temporary, placed at
-// the same address by the allocator, then overwrote the zeroed ticket counter and the fused
-// compaction returned without writing its offsets.  A kernel node keeps its place in the chain.
+// a graph node of its own, and with the HIP runtime inside this image's PyTorch wheel such a node
+// writes zero on the first replay only and an arbitrary word afterwards (csrc/graphfix.hip): the
+// ticket counter then started above the tile count, every tile of the fused compaction returned
+// without writing its offsets, and the scatter behind it read somebody else's bytes as offsets.
 __global__ __launch_bounds__(256) void zero_words_kernel(unsigned long long* __restrict__ w, long long n)
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) w[i] = 0ull;

@@ -1,9 +1,9 @@
 // Repair pass over a captured HIP graph: every memset node becomes a kernel node.
 //
 // No counterpart in the reference.  Why it exists: with the HIP runtime that ships inside this
-// image's PyTorch wheel (7.0.51831), a memset captured into a graph takes effect on the first
-// launch of the instantiated graph only -- from the second replay on the destination keeps
-// whatever the previous replay left there.  PyTorch's own reductions are hit (a column sum of a
+// image's PyTorch wheel (7.0.51831), a memset captured into a graph writes the captured value on
+// the first launch of the instantiated graph only -- from the second replay on the node fills its
+// destination with an arbitrary word (graph [memset buf = 0][out = buf]: 0, then -31456768, ...).  PyTorch's own reductions are hit (a column sum of a
 // 640 x 3920 matrix zeroes its semaphores with cudaMemsetAsync: 19 of 20 replays wrong,
 // tools/graph_memset_probe.py), and so was this library's single-pass compaction (ticket counter)
 // before it zeroed its workspace with a kernel.  lvmhelpers/graphs.py keeps the captured

@@ -31,7 +31,8 @@ import torch
 def capture(fn):
     """Runs fn() under stream capture and returns (graph, memset nodes replaced).  The captured
     graph goes through the library's repair pass before it is instantiated: with the HIP runtime
-    inside this image's PyTorch wheel a captured memset works on the first replay only, and
+    inside this image's PyTorch wheel a captured memset writes its value on the first replay only
+    (an arbitrary word afterwards), and
     PyTorch's reductions zero their semaphores with one (include/sparsemarg.h,
     smlvm_graph_memsets_to_kernels; tools/graph_memset_probe.py shows the failure without it)."""
     from . import _native
