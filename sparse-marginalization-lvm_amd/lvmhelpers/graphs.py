@@ -20,7 +20,11 @@ which gives a capture its own pool.  The optimiser must keep its state on the de
 `Marginalizer(compact=True)` has the same mode (all B * K pairs, or B * static_cap of them with an
 overflow flag that is checked every `check_every` steps).
 
-Limits: fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
+The static-shape modes apply in training mode only: after `model.eval()` the modules return the
+data-dependent shapes again (evaluation code such as the importance-sampling estimate walks `idxs`
+and does not expect padding).
+
+Limits: one process (no gradient all-reduce inside the graph); fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
 static-shape mode pays for B * k (top-k) or B * (n + 1) (SparseMAP) decoder rows instead of the
 support's, which is the right trade where a step is launch bound and the wrong one where the
 decoder dominates (config 5: 1024 samples of 128 bits per GPU).
@@ -67,6 +71,8 @@ class GraphedStep:
         for group in optimizer.param_groups:
             if 'capturable' in group and not group['capturable']:
                 raise ValueError("GraphedStep: the optimiser must be created with capturable=True")
+        if not model.training:
+            raise ValueError("GraphedStep: the model must be in training mode (model.train())")
         self.model = model
         self.optimizer = optimizer
         self.check_every = check_every

@@ -119,7 +119,7 @@ class Marginalizer(torch.nn.Module):
                          encoder_probs, encoder_entropy):
         batch_size, latent_size = encoder_probs.shape
         overflow = None
-        if self.static_shapes:
+        if self.static_shapes and self.training:
             n_cap = None if self.static_cap is None else batch_size * min(latent_size, int(self.static_cap))
             off, rows, cols, vals, n_total = _native.support_compact_fused(
                 encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True,
@@ -185,7 +185,7 @@ class Marginalizer(torch.nn.Module):
         if self.compact:
             return self._forward_compact(encoder_input, decoder_input, labels, discrete_latent_z,
                                          encoder_probs, encoder_entropy)
-        if self.static_shapes:
+        if self.static_shapes and self.training:
             raise RuntimeError("Marginalizer: static_shapes needs compact=True (the reference-order "
                                "column loop reads the live columns back on the host)")
         entropy_loss = -(encoder_entropy.mean() * self.encoder_entropy_coeff)

@@ -69,7 +69,8 @@ class TopKSparsemaxMarg(torch.nn.Module):
         # True: shapes that do not depend on the data and no host synchronisation -- all B * k
         # (row, slot) pairs go through the decoder, the ones with p = 0 behind the real ones as
         # (row 0, slot 0) with weight 0 -- so that a whole step can be captured in a HIP graph
-        # (lvmhelpers/graphs.py).  Same loss and gradients.
+        # (lvmhelpers/graphs.py).  Same loss and gradients.  Training mode only: in eval() the module
+        # keeps the data-dependent shapes, whose consumers do not expect padding.
         self.static_shapes = False
 
     def forward(self, encoder_input, decoder_input, labels):
@@ -78,7 +79,7 @@ class TopKSparsemaxMarg(torch.nn.Module):
         entropy_loss = -(encoder_entropy * self.encoder_entropy_coeff)
 
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
-        if self.static_shapes:
+        if self.static_shapes and self.training:
             off, rows, cols, vals, _ = _native.support_compact_fused(
                 encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True)
         else:
@@ -180,8 +181,8 @@ class SparseMAPWrapper(nn.Module):
 
     def forward(self, *args, **kwargs):
         scores = self.agent(*args, **kwargs)
-        if self.static_shapes:
-            return self._forward_static(scores)
+        if self.static_shapes and self.training:   # (evaluation keeps the data-dependent shapes:
+            return self._forward_static(scores)     #  its consumers -- importance sampling -- do not expect padding)
         batch_size, latent_size = scores.shape
         init_scores = None
         if self.init:

@@ -222,3 +222,19 @@ def test_static_cap_and_its_overflow_flag(dev):
     step(*batch)
     with pytest.raises(RuntimeError):
         step(*batch)
+
+
+def test_static_shapes_are_for_training_mode_only(dev):
+    """After eval() the modules return the data-dependent shapes even with static_shapes on
+    (evaluation code walks `idxs` / `support` and does not expect padding)."""
+    model, batch = _bitvae(dev, "sparsemap", 8, 16)
+    for m in model.modules():
+        if hasattr(m, 'static_shapes'):
+            m.static_shapes = True
+    out = model(*batch)
+    assert torch.is_tensor(out['log']['idxs']) and out['log']['loss_output'].numel() == 8 * 17
+    model.eval()
+    with torch.no_grad():
+        out = model(*batch)
+    assert isinstance(out['log']['idxs'], list)
+    assert out['log']['loss_output'].numel() == len(out['log']['idxs']) == sum(out['log']['support'].int().tolist())
