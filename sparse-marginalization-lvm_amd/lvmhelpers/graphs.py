@@ -24,7 +24,9 @@ The static-shape modes apply in training mode only: after `model.eval()` the mod
 data-dependent shapes again (evaluation code such as the importance-sampling estimate walks `idxs`
 and does not expect padding).
 
-Limits: one process (no gradient all-reduce inside the graph); fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
+Limits: one process (no gradient all-reduce inside the graph); hyper-parameters that are Python
+numbers are baked in at capture -- a learning-rate schedule needs the rate as a tensor
+(`Adam(lr=torch.tensor(1e-3, device=...), capturable=True)`, updated in place); fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
 static-shape mode pays for B * k (top-k) or B * (n + 1) (SparseMAP) decoder rows instead of the
 support's, which is the right trade where a step is launch bound and the wrong one where the
 decoder dominates (config 5: 1024 samples of 128 bits per GPU).
