@@ -81,6 +81,38 @@ def support_logsumexp(values, idxs, batch_size, shift=0.0):
     return _native.segmented_logsumexp(values.detach().to(torch.float32).contiguous(), off, shift)
 
 
+class _EmbedPairs(torch.autograd.Function):
+    """weight[idx] for the N (row, symbol) pairs of a step.  Forward: one gather.  Backward:
+    onehot(idx)^T @ grad as ONE dense GEMM [V, N] x [N, emb] -- deterministic, and 10-20 us where
+    torch's embedding_dense_backward walks the indices feature block by feature block (178 us for
+    the signal game's 2048 pairs into a 256 x 256 table, the largest kernel of that step)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        ctx.save_for_backward(idx)
+        ctx.vocab = weight.shape[0]
+        return weight.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        onehot = torch.zeros((idx.shape[0], ctx.vocab), dtype=g.dtype, device=g.device)
+        onehot.scatter_(1, idx.unsqueeze(1), 1.0)
+        return onehot.t().mm(g), None
+
+
+_EMBED_PAIRS_MAX = 1 << 26     # one-hot entries (256 MB of fp32) up to which the GEMM form is used
+
+
+def embed_pairs(embedding, idx):
+    """embedding(idx) for a 1-D idx; through _EmbedPairs when `embedding` is a plain nn.Embedding."""
+    plain = (isinstance(embedding, torch.nn.Embedding) and embedding.max_norm is None
+             and not embedding.scale_grad_by_freq and not embedding.sparse and embedding.padding_idx is None)
+    if plain and idx.dim() == 1 and idx.is_cuda and idx.numel() * embedding.num_embeddings <= _EMBED_PAIRS_MAX:
+        return _EmbedPairs.apply(embedding.weight, idx)
+    return embedding(idx)
+
+
 class HoistedReceiver:
     """The two-phase view of a module shaped like the signal game's Receiver
     (experiments/signal-game/archs.py:59-105): ``return_embeddings(x) -> [B, game_size, emb]`` and a
@@ -96,7 +128,7 @@ class HoistedReceiver:
         signal = z
         if signal.dim() == 3:
             signal = signal.squeeze(dim=-1)
-        h_s = self.receiver.lin2(signal)                              # [N, emb]
+        h_s = embed_pairs(self.receiver.lin2, signal)                 # [N, emb]
         out = torch.bmm(embeddings.index_select(0, rows), h_s.unsqueeze(-1)).squeeze(-1)
         return F.log_softmax(out, dim=1)
 

@@ -477,3 +477,24 @@ def test_empty_batches(dev):
     loss, lse, nll = _native.lowrank_ce_fwd(torch.empty(0, 5, 3, device=dev), torch.randn(7, 3, device=dev),
                                             torch.randn(7, device=dev), torch.empty(0, 5, dtype=torch.uint8, device=dev))
     assert loss.numel() == 0 and tuple(lse.shape) == (0, 5)
+
+
+def test_embed_pairs_gradient_is_the_embedding_gradient(dev):
+    """fused.embed_pairs: the lookup of the hoisted Receiver's message embedding, whose backward is a
+    one-hot GEMM instead of torch's embedding_dense_backward -- same values, same gradient (a sum in
+    another order), repeated and unused symbols included; other kinds of embedding fall through."""
+    from lvmhelpers import fused
+    torch.manual_seed(0)
+    emb = torch.nn.Embedding(37, 24).to(dev)
+    ref = torch.nn.Embedding(37, 24).to(dev)
+    ref.load_state_dict(emb.state_dict())
+    idx = torch.randint(0, 30, (500,), device=dev)          # symbols 30..36 never used
+    w = torch.randn(500, 24, device=dev)
+    out = fused.embed_pairs(emb, idx)
+    (out * w).sum().backward()
+    (ref(idx) * w).sum().backward()
+    assert torch.equal(out, ref(idx))
+    assert float((emb.weight.grad - ref.weight.grad).abs().max()) <= 1e-5 * float(ref.weight.grad.abs().max())
+    assert float(emb.weight.grad[30:].abs().max()) == 0.0
+    padded = torch.nn.Embedding(37, 24, padding_idx=0).to(dev)
+    assert fused.embed_pairs(padded, idx).grad_fn.name().startswith("Embedding")
