@@ -204,6 +204,14 @@ int smlvm_support_entropy_bwd(const float* vals, const float* gtotal, float inv_
                               int64_t N, void* stream);
 int smlvm_support_scatter(const float* g, const int64_t* row_offsets, const int32_t* cols, float* out,
                           int64_t R, int32_t K, void* stream);
+/* out [R, D] = per-row sums of g [N, D] over each row's compacted entries [row_offsets[r],
+ * row_offsets[r+1]), in entry order (fixed-order fp32 sums; entries at or beyond row_offsets[R] are
+ * ignored): the backward of gathering one vector per compacted entry from a per-row table, e.g. the
+ * signal game's candidate embeddings `embeddings[rows]` (experiments/signal-game/archs.py:76-89 run
+ * on the support's (row, symbol) pairs), which torch's index_select backward sums with float
+ * atomics.  R <= 65535 (SMLVM_ERR_UNSUPPORTED beyond). */
+int smlvm_support_segment_sum(const float* g, const int64_t* row_offsets, float* out, int64_t R,
+                              int64_t D, void* stream);
 size_t smlvm_weighted_loss_reduce_workspace_bytes(int64_t N);
 int smlvm_weighted_loss_reduce_fwd(const float* vals, const float* comps, const int64_t* row_offsets,
                                    float* row_out, float* total, float inv_b, int64_t R, int64_t N,

@@ -931,6 +931,37 @@ __global__ __launch_bounds__(256) void plogp_bwd_kernel(const float* __restrict_
     }
 }
 
+// out[r, :] = sum of g[j, :] over the row's entries j in [row_offsets[r], row_offsets[r+1]), in the
+// order of j: the backward of gathering one [D]-vector per compacted entry out of a per-row table
+// (state[rows]: the compaction is row-major, so a row's entries are contiguous).  torch's
+// index_select backward adds with float atomics, in an order that changes from run to run; this is
+// a fixed-order sum.  A thread owns one column of one row (float4 when D allows), so every load is
+// coalesced across the block and nothing is reduced across lanes.
+template <bool VEC>
+__global__ __launch_bounds__(256) void support_segment_sum_kernel(const float* __restrict__ g,
+                                                                  const int64_t* __restrict__ row_offsets,
+                                                                  float* __restrict__ out, int64_t R, int64_t D)
+{
+    const int64_t r = blockIdx.y;
+    const int64_t lo = row_offsets[r], hi = row_offsets[r + 1];
+    if constexpr (VEC) {
+        const int64_t d4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (d4 * 4 >= D) return;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t j = lo; j < hi; ++j) {
+            const float4 v = reinterpret_cast<const float4*>(g + j * D)[d4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(out + r * D)[d4] = acc;
+    } else {
+        const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (d >= D) return;
+        float acc = 0.f;
+        for (int64_t j = lo; j < hi; ++j) acc += g[j * D + d];
+        out[r * D + d] = acc;
+    }
+}
+
 // out[r, :] = 0 except out[r, cols[j]] = g[j] for the row's entries j in [row_offsets[r],
 // row_offsets[r+1]): the backward of gathering the compacted values out of a dense [R, K] tensor
 // (positions are distinct, so nothing has to be sorted or accumulated).  One wave per row.
@@ -1322,6 +1353,22 @@ extern "C" int smlvm_support_scatter(const float* g, const int64_t* row_offsets,
     if (!g || !cols) return SMLVM_ERR_INVALID;
     if ((R + 3) / 4 > 0x7fffffffll) return SMLVM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(support_scatter_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, row_offsets, cols, out, R, K);
+    return check_launch();
+}
+
+extern "C" int smlvm_support_segment_sum(const float* g, const int64_t* row_offsets, float* out,
+                                         int64_t R, int64_t D, void* stream)
+{
+    if (R < 0 || D < 1) return SMLVM_ERR_INVALID;
+    if (R == 0) return SMLVM_OK;
+    if (!row_offsets || !out || !g) return SMLVM_ERR_INVALID;
+    if (R > 65535) return SMLVM_ERR_UNSUPPORTED;          // (grid.y; batches, not matrices of rows)
+    const bool vec = D % 4 == 0 && aligned16(g) && aligned16(out);
+    const int64_t cols = vec ? D / 4 : D;
+    if ((cols + 255) / 256 > 0x7fffffffll) return SMLVM_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)R);
+    if (vec) hipLaunchKernelGGL(support_segment_sum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, g, row_offsets, out, R, D);
+    else hipLaunchKernelGGL(support_segment_sum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, g, row_offsets, out, R, D);
     return check_launch();
 }
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsparsemarg_hip.so")
 _lib = None
 
 ABI_SYMBOLS = [
-    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error", "smlvm_graph_memsets_to_kernels",
+    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error", "smlvm_graph_memsets_to_kernels", "smlvm_support_segment_sum",
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy", "smlvm_entmax15_fwd", "smlvm_entmax15_bwd",
     "smlvm_entmax15_fwd_lists", "smlvm_entmax15_bwd_lists",
@@ -480,6 +480,26 @@ def support_entropy_bwd(vals, gtotal, inv_b=1.0):
         _check(lib().smlvm_support_entropy_bwd(_p(vals), _p(gtotal), _f32(inv_b), _p(dvals),
                                                _i64(vals.numel()), _stream()), "smlvm_support_entropy_bwd")
     return dvals
+
+
+def support_segment_sum(g, row_offsets, R):
+    """g [N, ...] -> [R, ...]: per-row sums over each row's compacted entries (row_offsets [R+1]),
+    in entry order; entries at or beyond row_offsets[R] (static-shape padding) are ignored."""
+    g = _need_gpu(g, torch.float32, "g")
+    row_offsets = _need_gpu(row_offsets, torch.int64, "row_offsets")
+    if row_offsets.shape[0] != R + 1:
+        raise ValueError("support_segment_sum: row_offsets must be [R+1]")
+    inner = tuple(g.shape[1:])
+    D = 1
+    for v in inner:
+        D *= v
+    out = torch.empty((R,) + inner, dtype=torch.float32, device=g.device)
+    if g.shape[0] == 0 or D == 0:
+        return out.zero_()
+    with torch.cuda.device(g.device):
+        _check(lib().smlvm_support_segment_sum(_p(g), _p(row_offsets), _p(out), _i64(R), _i64(D), _stream()),
+               "smlvm_support_segment_sum")
+    return out
 
 
 def support_scatter(g, row_offsets, cols, R, K):

@@ -160,6 +160,29 @@ class _GatherSupport(torch.autograd.Function):
         return _native.support_scatter(g.contiguous(), row_offsets, cols, R, K), None, None, None
 
 
+class _GatherRows(torch.autograd.Function):
+    """table[rows] for the compaction's (sorted, row-major) rows.  The backward sums each row's
+    entries in order with one kernel (smlvm_support_segment_sum) instead of torch's index_select
+    backward, which adds with float atomics in an order that changes from run to run."""
+
+    @staticmethod
+    def forward(ctx, table, rows, row_offsets):
+        ctx.save_for_backward(row_offsets)
+        ctx.R = table.shape[0]
+        return table.index_select(0, rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (row_offsets,) = ctx.saved_tensors
+        return _native.support_segment_sum(g.contiguous(), row_offsets, ctx.R), None, None
+
+
+def gather_rows(table, rows, row_offsets):
+    """table [R, ...] gathered at the compaction's rows [N] (int64, row-major order) with a
+    deterministic backward; row_offsets [R+1] are the compaction's."""
+    return _GatherRows.apply(table, rows, row_offsets)
+
+
 def gather_support(p, row_offsets, cols, vals):
     """The compacted probabilities `vals` (== p[rows, cols], row-major) as a differentiable function
     of p [R, K]."""

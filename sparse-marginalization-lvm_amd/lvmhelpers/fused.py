@@ -124,12 +124,19 @@ class HoistedReceiver:
     def embed_once(self, decoder_input):
         return self.receiver.return_embeddings(decoder_input)
 
-    def decode_pairs(self, z, embeddings, rows):
+    takes_row_offsets = True      # (Marginalizer then hands the compaction's offsets over as well)
+
+    def decode_pairs(self, z, embeddings, rows, row_offsets=None):
         signal = z
         if signal.dim() == 3:
             signal = signal.squeeze(dim=-1)
         h_s = embed_pairs(self.receiver.lin2, signal)                 # [N, emb]
-        out = torch.bmm(embeddings.index_select(0, rows), h_s.unsqueeze(-1)).squeeze(-1)
+        if row_offsets is not None and embeddings.dtype == torch.float32 and embeddings.is_cuda \
+                and embeddings.shape[0] <= 65535:
+            gathered = F_.gather_rows(embeddings.contiguous(), rows, row_offsets)
+        else:
+            gathered = embeddings.index_select(0, rows)
+        out = torch.bmm(gathered, h_s.unsqueeze(-1)).squeeze(-1)
         return F.log_softmax(out, dim=1)
 
 

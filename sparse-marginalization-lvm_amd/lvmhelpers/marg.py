@@ -156,7 +156,11 @@ class Marginalizer(torch.nn.Module):
             raise TypeError("Marginalizer(hoist=True): the decoder defines neither embed_once/"
                             "decode_pairs nor return_embeddings/lin2")
         if two_phase is not None:
-            decoder_output = two_phase.decode_pairs(cols_l, two_phase.embed_once(decoder_input), rows_l)
+            if getattr(two_phase, 'takes_row_offsets', False):
+                decoder_output = two_phase.decode_pairs(cols_l, two_phase.embed_once(decoder_input), rows_l,
+                                                        row_offsets=off)
+            else:
+                decoder_output = two_phase.decode_pairs(cols_l, two_phase.embed_once(decoder_input), rows_l)
             decoder_input_sel = take(decoder_input, self.batch_dims[1])
         else:
             decoder_input_sel = take(decoder_input, self.batch_dims[1])

@@ -386,3 +386,34 @@ def test_gather_support_is_the_indexing_it_replaces(dev, R, K):
     dense = _native.support_scatter(w, off, cols, R, K)
     assert torch.equal(dense, pb.grad)
 
+
+@pytest.mark.parametrize("R,inner,dens", [(64, (16, 256), 0.03), (7, (5,), 0.5), (300, (33,), 0.1), (1, (8,), 1.0),
+                                          (40, (4, 3, 2), 0.0)])
+def test_segment_sum_is_the_gather_backward(dev, oracle_mod, R, inner, dens):
+    """smlvm_support_segment_sum / functional.gather_rows: per-row sums of one vector per compacted
+    entry == the backward of table[rows] (index_add), with empty rows, and with static-shape padding
+    behind the N real entries ignored; and it is the same to the last bit on every call."""
+    from lvmhelpers import _native, functional as F_
+    rng = np.random.default_rng(R + len(inner))
+    p = rng.random((R, 12)).astype(np.float32)
+    p[rng.random((R, 12)) >= dens] = 0.0
+    off, rows, _, _ = oracle_mod.support_compact(p)
+    N, pad = rows.shape[0], 5
+    g = rng.standard_normal((N + pad,) + inner).astype(np.float32)
+    want = np.zeros((R,) + inner, np.float64)
+    np.add.at(want, rows, g[:N].astype(np.float64))
+    offt = torch.from_numpy(off).to(dev)
+    got = _native.support_segment_sum(torch.from_numpy(g).to(dev), offt, R)
+    assert tuple(got.shape) == (R,) + inner
+    assert np.abs(got.cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert torch.equal(got, _native.support_segment_sum(torch.from_numpy(g).to(dev), offt, R))
+    # as an autograd function
+    table = torch.randn((R,) + inner, device=dev, requires_grad=True)
+    rows_t = torch.from_numpy(np.concatenate([rows, np.zeros(pad, np.int32)])).to(dev).long()
+    w = torch.from_numpy(g).to(dev)
+    w[N:] = 0.0                                               # (padding carries no gradient)
+    (F_.gather_rows(table, rows_t, offt) * w).sum().backward()
+    ref = torch.randn(1)  # placeholder to keep names distinct
+    t2 = table.detach().clone().requires_grad_(True)
+    (t2.index_select(0, rows_t) * w).sum().backward()
+    assert float((table.grad - t2.grad).abs().max()) <= 1e-5 * max(1.0, float(t2.grad.abs().max()))
