@@ -24,6 +24,9 @@ The static-shape modes apply in training mode only: after `model.eval()` the mod
 data-dependent shapes again (evaluation code such as the importance-sampling estimate walks `idxs`
 and does not expect padding).
 
+`eager_for_other_shapes=True` runs a batch of another shape (an epoch's last one) eagerly through
+the same model and optimiser instead of raising.
+
 Limits: one process (no gradient all-reduce inside the graph); hyper-parameters that are Python
 numbers are baked in at capture -- a learning-rate schedule needs the rate as a tensor
 (`Adam(lr=torch.tensor(1e-3, device=...), capturable=True)`, updated in place); fixed batch shape (a last, smaller batch needs its own GraphedStep or an eager step); the
@@ -67,7 +70,7 @@ class GraphedStep:
     generator back to where they were, so that creating a GraphedStep does not train.
     """
 
-    def __init__(self, model, optimizer, batch, warmup=3, check_every=50):
+    def __init__(self, model, optimizer, batch, warmup=3, check_every=50, eager_for_other_shapes=False):
         if not all(torch.is_tensor(t) and t.is_cuda for t in batch):
             raise ValueError("GraphedStep: the batch must be a tuple of GPU tensors")
         for group in optimizer.param_groups:
@@ -78,6 +81,7 @@ class GraphedStep:
         self.model = model
         self.optimizer = optimizer
         self.check_every = check_every
+        self.eager_for_other_shapes = eager_for_other_shapes
         self._calls = 0
         self.static_batch = tuple(t.clone() for t in batch)
         self._switched = _set_static(model, True)
@@ -139,12 +143,18 @@ class GraphedStep:
         if len(batch) != len(self.static_batch):
             raise ValueError("GraphedStep: the batch has another number of tensors than the captured one")
         for dst, src in zip(self.static_batch, batch):
-            if src is dst:
-                continue
             if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
+                if self.eager_for_other_shapes:     # an epoch's last, smaller batch: the same step, eagerly
+                    self.optimizer.zero_grad(set_to_none=False)   # (the graph owns the .grad tensors)
+                    out = self.model(*batch)
+                    out['loss'].backward()
+                    self.optimizer.step()
+                    return out
                 raise ValueError("GraphedStep: batch shapes and dtypes are fixed at capture "
                                  f"({tuple(dst.shape)} {dst.dtype}, got {tuple(src.shape)} {src.dtype})")
-            dst.copy_(src, non_blocking=True)
+        for dst, src in zip(self.static_batch, batch):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
         for m in self._refreshers:
             m.refresh_static()
         self.graph.replay()

@@ -238,3 +238,29 @@ def test_static_shapes_are_for_training_mode_only(dev):
         out = model(*batch)
     assert isinstance(out['log']['idxs'], list)
     assert out['log']['loss_output'].numel() == len(out['log']['idxs']) == sum(out['log']['support'].int().tolist())
+
+
+def test_a_batch_of_another_shape_runs_eagerly_on_request(dev):
+    """eager_for_other_shapes=True: an epoch's last, smaller batch goes through the same model and
+    optimiser eagerly, and the captured step still works afterwards."""
+    from lvmhelpers.graphs import GraphedStep
+    B = 16
+    model, batch0 = _bitvae(dev, "topk", B, 16)
+    twin = copy.deepcopy(model)
+    for m in twin.modules():
+        if hasattr(m, 'static_shapes'):
+            m.static_shapes = True
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    opt_twin = torch.optim.SGD(twin.parameters(), lr=1e-3)
+    step = GraphedStep(model, opt, batch0, eager_for_other_shapes=True)
+    full = _batches(dev, B, 2, 4)
+    small = tuple(t[:5] for t in _batches(dev, B, 1, 8)[0])
+    for b in (full[0], small, full[1]):
+        out = step(*b)
+        opt_twin.zero_grad(set_to_none=True)
+        o2 = twin(*b)
+        o2['loss'].backward()
+        opt_twin.step()
+        assert abs(float(out['loss'].detach()) - float(o2['loss'].detach())) <= 1e-6 * abs(float(o2['loss'].detach()))
+    for p, q in zip(model.parameters(), twin.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-6 * max(1.0, float(q.detach().abs().max()))
