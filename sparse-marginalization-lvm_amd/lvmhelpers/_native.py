@@ -79,8 +79,36 @@ def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
+# Host cost of a call: at the reference's batch size a step is a chain of ~10 of these wrappers and
+# the GPU waits for each.  The raw stream handle and the device check go straight to torch._C (no
+# Stream object, no context manager when the tensor's device is already current): 11.3 -> ~7 us per
+# call (tools/t_host_overhead.py; a torch elementwise op costs 4.3 us).
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def _on(dev):
+    """Context that makes `dev` the current device -- nothing at all when it already is."""
+    if _raw_device is not None and dev.index is not None and _raw_device() == dev.index:
+        return _NOOP
+    return torch.cuda.device(dev)
 
 
 def _need_gpu(t, dtype, name):
@@ -127,7 +155,7 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
     tau = torch.empty(R, dtype=torch.float32, device=x.device) if want_tau else None
     ent = torch.empty(R, dtype=torch.float32, device=x.device) if want_entropy else None
     if not want_cols:
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _check(lib().smlvm_sparsemax_fwd(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
                                              _i64(R), _i32(K), _stream()), "smlvm_sparsemax_fwd")
         return p, supp, nnz, tau, ent
@@ -140,7 +168,7 @@ def sparsemax_fwd(x, want_nnz=False, want_tau=False, want_entropy=False, want_co
             # zeroed: a row is only ever marked -3 after its bits were written, this is defence
             mask = torch.zeros(nbytes // 4, dtype=torch.int32, device=x.device)
     vals = torch.empty((R, cap), dtype=torch.float32, device=x.device) if (want_vals and K <= 4096) else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         if vals is not None:
             _check(lib().smlvm_sparsemax_fwd_lists(_p(x), _p(p), _p(supp), _p(nnz), _p(tau), _p(ent),
                                                    _p(cols), _p(vals), _i32(cap), _p(mask), _i64(R),
@@ -165,7 +193,7 @@ def sparsemax_bwd_cols(dy, cols, p, supp, mask=None):
         if mask.numel() * 4 < lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K)):
             raise ValueError("support mask too small for this shape")
     dx = torch.empty_like(p)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_sparsemax_bwd_cols(_p(dy), _p(cols), _i32(cols.shape[1]), _p(mask), _p(p),
                                               _p(supp), _p(dx), _i64(R), _i32(K), _stream()),
                "smlvm_sparsemax_bwd_cols")
@@ -178,7 +206,7 @@ def sparsemax_bwd(dy, p, supp):
     supp = _need_gpu(supp, torch.int32, "supp_size")
     R, K = p.shape
     dx = torch.empty_like(p)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_sparsemax_bwd(_p(dy), _p(p), _p(supp), _p(dx), _i64(R), _i32(K),
                                          _stream()), "smlvm_sparsemax_bwd")
     return dx
@@ -188,7 +216,7 @@ def entropy(p):
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     out = torch.empty(R, dtype=torch.float32, device=p.device)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_entropy(_p(p), _p(out), _i64(R), _i32(K), _stream()), "smlvm_entropy")
     return out
 
@@ -200,7 +228,7 @@ def entmax15_fwd(x, want_nnz=False, want_tau=False):
     p = torch.empty_like(x)
     nnz = torch.empty(R, dtype=torch.int32, device=x.device) if want_nnz else None
     tau = torch.empty(R, dtype=torch.float32, device=x.device) if want_tau else None
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().smlvm_entmax15_fwd(_p(x), _p(p), _p(nnz), _p(tau), _i64(R), _i32(K), _stream()),
                "smlvm_entmax15_fwd")
     return p, nnz, tau
@@ -221,7 +249,7 @@ def entmax15_fwd_lists(x, cap=ENTMAX15_LIST_CAP):
     p = torch.empty_like(x)
     cols = torch.empty((R, cap), dtype=torch.int32, device=x.device)
     vals = torch.empty((R, cap), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _check(lib().smlvm_entmax15_fwd_lists(_p(x), _p(p), None, None, _p(cols), _p(vals), _i32(cap),
                                               _i64(R), _i32(K), _stream()), "smlvm_entmax15_fwd_lists")
     return p, cols, vals
@@ -236,7 +264,7 @@ def entmax15_bwd_lists(dy, p, cols, vals):
     if tuple(cols.shape) != tuple(vals.shape) or cols.shape[0] != R:
         raise ValueError("support_cols / support_vals must be [R, cap]")
     dx = torch.empty_like(p)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_entmax15_bwd_lists(_p(dy), _p(p), _p(cols), _p(vals), _i32(cols.shape[1]), _p(dx),
                                               _i64(R), _i32(K), _stream()), "smlvm_entmax15_bwd_lists")
     return dx
@@ -247,7 +275,7 @@ def entmax15_bwd(dy, p):
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     dx = torch.empty_like(p)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_entmax15_bwd(_p(dy), _p(p), _p(dx), _i64(R), _i32(K), _stream()),
                "smlvm_entmax15_bwd")
     return dx
@@ -258,7 +286,7 @@ def support_count(p):
     p = _need_gpu(p, torch.float32, "p")
     R, K = p.shape
     nnz = torch.empty(R, dtype=torch.int32, device=p.device)
-    with torch.cuda.device(p.device):
+    with _on(p.device):
         _check(lib().smlvm_support_count(_p(p), _p(nnz), _i64(R), _i32(K), _stream()),
                "smlvm_support_count")
     return nnz
@@ -270,7 +298,7 @@ def support_offsets(nnz):
     off = torch.empty(R + 1, dtype=torch.int64, device=nnz.device)
     nbytes = lib().smlvm_support_offsets_workspace_bytes(R)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=nnz.device)
-    with torch.cuda.device(nnz.device):
+    with _on(nnz.device):
         _check(lib().smlvm_support_offsets(_p(nnz), _p(off), _i64(R), _p(ws),
                                            ctypes.c_size_t(nbytes), _stream()),
                "smlvm_support_offsets")
@@ -289,7 +317,7 @@ def support_row_offsets(p, nnz=None, support_cols=None):
         else:
             support_cols = _need_gpu(support_cols, torch.int32, "support_cols")
             nnz = torch.empty(R, dtype=torch.int32, device=p.device)
-            with torch.cuda.device(p.device):
+            with _on(p.device):
                 _check(lib().smlvm_support_count_cols(_p(p), _p(support_cols), _i32(support_cols.shape[1]),
                                                       _p(nnz), _i64(R), _i32(K), _stream()),
                        "smlvm_support_count_cols")
@@ -350,7 +378,7 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     rows = alloc(n_cap, dtype=torch.int32, device=dev) if want_rows else None
     cols = alloc(n_cap, dtype=torch.int32, device=dev) if want_cols else None
     vals = alloc(n_cap, dtype=torch.float32, device=dev) if want_vals else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
                                                  _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
                                                  _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
@@ -415,7 +443,7 @@ def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True,
     rows = torch.empty(N, dtype=torch.int32, device=dev) if want_rows else None
     cols = torch.empty(N, dtype=torch.int32, device=dev) if want_cols else None
     vals = torch.empty(N, dtype=torch.float32, device=dev) if want_vals else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if support_cols is None:
             _check(lib().smlvm_support_compact(_p(p), _p(off), _p(rows), _p(cols), _p(vals), _i64(R),
                                                _i32(K), _stream()), "smlvm_support_compact")
@@ -438,7 +466,7 @@ def weighted_loss_reduce_fwd(vals, comps, row_offsets=None, inv_b=1.0, want_rows
     total = torch.empty(1, dtype=torch.float32, device=dev)
     nbytes = lib().smlvm_weighted_loss_reduce_workspace_bytes(N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_weighted_loss_reduce_fwd(
             _p(vals), _p(comps), _p(row_offsets), _p(row_out), _p(total), _f32(inv_b), _i64(R),
             _i64(N), _p(ws), ctypes.c_size_t(nbytes), _stream()), "smlvm_weighted_loss_reduce_fwd")
@@ -452,7 +480,7 @@ def weighted_loss_reduce_bwd(vals, comps, gtotal, inv_b, want_dvals=True, want_d
     N = vals.shape[0]
     dvals = torch.empty_like(vals) if want_dvals else None
     dcomps = torch.empty_like(comps) if want_dcomps else None
-    with torch.cuda.device(vals.device):
+    with _on(vals.device):
         _check(lib().smlvm_weighted_loss_reduce_bwd(_p(vals), _p(comps), _p(gtotal), _f32(inv_b),
                                                     _p(dvals), _p(dcomps), _i64(N), _stream()),
                "smlvm_weighted_loss_reduce_bwd")
@@ -466,7 +494,7 @@ def support_entropy_fwd(vals, inv_b=1.0):
     total = torch.empty(1, dtype=torch.float32, device=vals.device)
     nbytes = lib().smlvm_weighted_loss_reduce_workspace_bytes(N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=vals.device)
-    with torch.cuda.device(vals.device):
+    with _on(vals.device):
         _check(lib().smlvm_support_entropy_fwd(_p(vals), _i64(N), _f32(inv_b), _p(total), _p(ws),
                                                ctypes.c_size_t(nbytes), _stream()), "smlvm_support_entropy_fwd")
     return total
@@ -476,7 +504,7 @@ def support_entropy_bwd(vals, gtotal, inv_b=1.0):
     vals = _need_gpu(vals, torch.float32, "vals")
     gtotal = _need_gpu(gtotal.reshape(1), torch.float32, "gtotal")
     dvals = torch.empty_like(vals)
-    with torch.cuda.device(vals.device):
+    with _on(vals.device):
         _check(lib().smlvm_support_entropy_bwd(_p(vals), _p(gtotal), _f32(inv_b), _p(dvals),
                                                _i64(vals.numel()), _stream()), "smlvm_support_entropy_bwd")
     return dvals
@@ -496,7 +524,7 @@ def support_segment_sum(g, row_offsets, R):
     out = torch.empty((R,) + inner, dtype=torch.float32, device=g.device)
     if g.shape[0] == 0 or D == 0:
         return out.zero_()
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         _check(lib().smlvm_support_segment_sum(_p(g), _p(row_offsets), _p(out), _i64(R), _i64(D), _stream()),
                "smlvm_support_segment_sum")
     return out
@@ -513,7 +541,7 @@ def support_scatter(g, row_offsets, cols, R, K):
     out = torch.empty((R, K), dtype=torch.float32, device=g.device)
     if g.shape[0] == 0:
         return out.zero_()
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         _check(lib().smlvm_support_scatter(_p(g), _p(row_offsets), _p(cols), _p(out), _i64(R), _i32(K),
                                            _stream()), "smlvm_support_scatter")
     return out
@@ -525,7 +553,7 @@ def binary_topk_batched(scores, k, want_scores=False):
     B, n = scores.shape
     cfg = torch.empty((B, k, n), dtype=torch.float32, device=scores.device)
     top = torch.empty((B, k), dtype=torch.float32, device=scores.device) if want_scores else None
-    with torch.cuda.device(scores.device):
+    with _on(scores.device):
         _check(lib().smlvm_binary_topk_batched(_p(scores), _p(cfg), _p(top), _i64(B), _i32(n),
                                                _i32(k), _stream()), "smlvm_binary_topk_batched")
     return cfg, top
@@ -555,7 +583,7 @@ def sparsemap_fwd(scores, init_scores=None, budget=0, max_iter=300):
         status=torch.empty(B, dtype=torch.int32, device=dev))
     ws_bytes = lib().smlvm_sparsemap_fwd_workspace_bytes(B, n, 1)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_sparsemap_fwd(
             _p(scores), _p(init_scores), _i32(int(budget)), _i32(int(max_iter)), _i64(B), _i32(n),
             _p(out["aset_bits"]), _p(out["p"]), _p(out["alen"]), _p(out["inv_a"]),
@@ -587,7 +615,7 @@ def sparsemap_seq_fwd(scores, trans, init_scores=None, max_iter=300):
         status=torch.empty(B, dtype=torch.int32, device=dev))
     ws_bytes = lib().smlvm_sparsemap_fwd_workspace_bytes(B, n, 1)
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_sparsemap_seq_fwd(
             _p(scores), _p(trans), _p(init_scores), _i32(int(max_iter)), _i64(B), _i32(n),
             _p(out["aset_bits"]), _p(out["p"]), _p(out["alen"]), _p(out["inv_a"]),
@@ -602,7 +630,7 @@ def sparsemap_seq_bwd(dp, aset_bits, alen, inv_a, n):
     B = dp.shape[0]
     dscores = torch.empty((B, n), dtype=torch.float32, device=dp.device)
     dtrans = torch.empty((B, n - 1), dtype=torch.float32, device=dp.device)
-    with torch.cuda.device(dp.device):
+    with _on(dp.device):
         _check(lib().smlvm_sparsemap_seq_bwd(_p(dp), _p(aset_bits), _p(alen), _p(inv_a), _i64(B),
                                              _i32(n), _p(dscores), _p(dtrans), _stream()),
                "smlvm_sparsemap_seq_bwd")
@@ -613,7 +641,7 @@ def sparsemap_bwd(dp, aset_bits, alen, inv_a, n):
     dp = _need_gpu(dp, torch.float32, "dp")
     B = dp.shape[0]
     dscores = torch.empty((B, n), dtype=torch.float32, device=dp.device)
-    with torch.cuda.device(dp.device):
+    with _on(dp.device):
         _check(lib().smlvm_sparsemap_bwd(_p(dp), _p(aset_bits), _p(alen), _p(inv_a), _i64(B),
                                          _i32(n), _p(dscores), _stream()), "smlvm_sparsemap_bwd")
     return dscores
@@ -622,7 +650,7 @@ def sparsemap_bwd(dp, aset_bits, alen, inv_a, n):
 def unpack_configs(aset_bits, rows, cols, n):
     N = rows.shape[0]
     out = torch.empty((N, n), dtype=torch.float32, device=aset_bits.device)
-    with torch.cuda.device(aset_bits.device):
+    with _on(aset_bits.device):
         _check(lib().smlvm_unpack_configs(_p(aset_bits), _p(rows), _p(cols), _p(out), _i64(N),
                                           _i32(n), _stream()), "smlvm_unpack_configs")
     return out
@@ -657,12 +685,12 @@ def lowrank_ce_fwd(x, w, b, y, want_dxdir=False):
     loss = torch.empty(N, dtype=torch.float32, device=dev)
     if want_dxdir:
         dxdir = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _check(lib().smlvm_lowrank_ce_fwd_dxdir(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(nll),
                                                     _p(loss), _p(dxdir), _i64(N), _i32(F), _i32(C), _i32(R),
                                                     _stream()), "smlvm_lowrank_ce_fwd_dxdir")
         return loss, lse, nll, dxdir
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_lowrank_ce_fwd(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(nll),
                                           _p(loss), _i64(N), _i32(F), _i32(C), _i32(R), _stream()),
                "smlvm_lowrank_ce_fwd")
@@ -685,7 +713,7 @@ def lowrank_ce_bwd(x, w, b, y, lse, gloss, want_dx=True, want_dw=True):
     db = (torch.empty_like(b) if N > 0 else torch.zeros_like(b)) if want_dw else None
     nbytes = lib().smlvm_lowrank_ce_bwd_workspace_bytes(N, F, C, R) if want_dw else 0
     ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _check(lib().smlvm_lowrank_ce_bwd(_p(x), _p(w), _p(b), _p(y), _i32(kind), _p(lse), _p(gloss),
                                           _p(dx), _p(dw), _p(db), _i64(N), _i32(F), _i32(C), _i32(R),
                                           _p(ws), ctypes.c_size_t(nbytes), _stream()),
@@ -699,7 +727,7 @@ def segmented_logsumexp(v, row_offsets, shift=0.0):
     row_offsets = _need_gpu(row_offsets, torch.int64, "row_offsets")
     R = row_offsets.shape[0] - 1
     out = torch.empty(R, dtype=torch.float32, device=v.device)
-    with torch.cuda.device(v.device):
+    with _on(v.device):
         _check(lib().smlvm_segmented_logsumexp(_p(v), _p(row_offsets), _f32(float(shift)), _p(out),
                                                _i64(R), _stream()), "smlvm_segmented_logsumexp")
     return out
