@@ -189,6 +189,19 @@ int smlvm_support_compact_fused(const float* p, const int32_t* support_cols, con
                                 int32_t cap, int64_t* row_offsets, int32_t* rows, int32_t* cols,
                                 float* vals, int64_t n_cap, int64_t R, int32_t K, void* workspace,
                                 size_t workspace_bytes, void* stream);
+/* smlvm_support_compact_fused with the forward's patterns: for 32 < K <= 1024 (K % 4 == 0)
+ * smlvm_sparsemax_fwd_cols / _fwd_lists leave, in `support_mask`, 16 bits per lane of EVERY row's
+ * non-zero pattern (smlvm_sparsemax_support_mask_bytes(R, K) bytes) when x and p are 16-byte aligned.
+ * Rows without a list (more non-zeros than cap) are then counted from those 2-64 bytes instead of
+ * from their K probabilities; the entries are still read from p.  Same outputs.  support_cols and
+ * support_mask must come from the same forward call as p (a mask buffer that the forward did not
+ * fill -- unaligned x, K % 4 != 0 -- gives wrong counts: the caller's to know). */
+int smlvm_support_compact_fused_masks(const float* p, const int32_t* support_cols,
+                                      const float* support_vals, int32_t cap,
+                                      const uint32_t* support_mask, int64_t* row_offsets,
+                                      int32_t* rows, int32_t* cols, float* vals, int64_t n_cap,
+                                      int64_t R, int32_t K, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 /* Entropy of the compacted distribution and the gather it is taken over.  Replaces
  * lvmhelpers/structmarg.py:51-54 and :200 (`-(distr @ torch.log(distr)) / batch_size`, seven
  * elementwise launches forward and six backward) and the advanced indexing `p[rows, cols]` of

@@ -557,11 +557,16 @@ __device__ __forceinline__ long long block_exclusive_scan_nw(long long v, long l
 
 // LR: no lists at all and K <= 64 -- a lane per row (below); a variant of its own, so that the
 // list-fed kernel keeps the code it was tuned with (as a run-time branch it cost that one 8 %)
-template <int G, bool VEC, bool LR = false>
+// PAT: rows without a list are COUNTED from the 16-bit-per-lane patterns the forward leaves for
+// every row of 32 < K <= 1024 (smlvm_sparsemax_support_mask_bytes: pat_dwords = lanes / 2 words per
+// row) instead of from their K probabilities -- a lane per row, one or two 16-byte loads, no
+// reduction; the entries themselves are still read from p in phase B.
+template <int G, bool VEC, bool LR = false, bool PAT = false>
 __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel(
     const float* __restrict__ p, const int32_t* __restrict__ lists, const float* __restrict__ vlists,
     int64_t* __restrict__ row_offsets, int32_t* __restrict__ rows, int32_t* __restrict__ cols,
-    float* __restrict__ vals, int64_t n_cap, int64_t R, int K, unsigned long long* __restrict__ ws)
+    float* __restrict__ vals, int64_t n_cap, int64_t R, int K, unsigned long long* __restrict__ ws,
+    const uint32_t* __restrict__ patterns = nullptr, int pat_dwords = 0)
 {
     constexpr int RW = 64 / G, S = G, CAP = 4 * G;
     __shared__ int cnt[kFusedTileRows];
@@ -623,7 +628,33 @@ __global__ __launch_bounds__(64 * kFusedWaves) void support_compact_fused_kernel
     // dependent round trips for a tile of 64 rows -- 47 us for the 64 x 33 batch of the 32-bit VAE,
     // which the host then waits for (it reads the offsets back).
     constexpr bool lane_rows = LR;
-    if constexpr (lane_rows) {
+    if constexpr (PAT) {
+        // (the listed rows' counts are in cnt[] already, 0 for the unlisted ones of this slice)
+        unsigned long long unl_any = 0ull;
+#pragma unroll
+        for (int s = 0; s < S; ++s) unl_any |= unl_steps[s];
+        if (unl_any != 0ull) {                 // wave-uniform
+            // which rows of the slice are unlisted: slice row i = s * RW + grp has its flag at bit
+            // grp * G of unl_steps[s]; parked as one byte per row in this wave's LDS
+            unsigned char* flag = reinterpret_cast<unsigned char*>(parked[wave]);
+            wave_lds_sync();
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (gl == 0) flag[s * RW + grp] = (unsigned char)((unl_steps[s] >> (grp * G)) & 1ull);
+            wave_lds_sync();
+            const int64_t r = row_base + lane;
+            if (r < R && flag[lane]) {
+                const uint4* pr = reinterpret_cast<const uint4*>(patterns + r * pat_dwords);
+                int c = 0;
+                for (int d = 0; d < (pat_dwords >> 2); ++d) {
+                    const uint4 w = pr[d];
+                    c += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+                }
+                cnt[wave * 64 + lane] = c;
+            }
+            wave_lds_sync();
+        }
+    } else if constexpr (lane_rows) {
         const int64_t r = row_base + lane;
         int c = 0;
         if (r < R) {
@@ -1257,6 +1288,43 @@ extern "C" int smlvm_support_compact_fused(const float* p, const int32_t* suppor
     else if (support_cols && cap == 64) { SMLVM_FUSED(16); }
     else { SMLVM_FUSED(8); }
 #undef SMLVM_FUSED
+    return check_launch();
+}
+
+extern "C" int smlvm_support_compact_fused_masks(const float* p, const int32_t* support_cols,
+                                                 const float* support_vals, int32_t cap,
+                                                 const uint32_t* support_mask, int64_t* row_offsets,
+                                                 int32_t* rows, int32_t* cols, float* vals,
+                                                 int64_t n_cap, int64_t R, int32_t K, void* workspace,
+                                                 size_t workspace_bytes, void* stream)
+{
+    if (R < 0 || K < 1 || n_cap < 0 || !row_offsets) return SMLVM_ERR_INVALID;
+    if (!support_cols || !support_mask || !(cap == 16 || cap == 32 || cap == 64)) return SMLVM_ERR_INVALID;
+    if (!aligned16(support_cols) || !aligned16(support_mask)) return SMLVM_ERR_INVALID;
+    if (support_vals && !aligned16(support_vals)) return SMLVM_ERR_INVALID;
+    // the forward leaves 16-bit patterns for the 16-register tiles of its vector path only
+    if (K <= 32 || K > 1024 || K % 4 != 0) return SMLVM_ERR_UNSUPPORTED;
+    const size_t need = smlvm_support_compact_fused_workspace_bytes(R);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return SMLVM_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    zero_words(workspace, need, st);
+    if (R == 0) {
+        zero_words(row_offsets, sizeof(int64_t), st);
+        return SMLVM_OK;
+    }
+    if (!p) return SMLVM_ERR_INVALID;
+    const bool vec = aligned16(p);
+    const int lanes = K <= 128 ? 8 : (K <= 256 ? 16 : (K <= 512 ? 32 : 64));   // as smlvm_sparsemax_support_mask_bytes
+    const int pat_dwords = lanes / 2;
+    const unsigned grid = (unsigned)((R + kFusedTileRows - 1) / kFusedTileRows);
+    unsigned long long* ws = static_cast<unsigned long long*>(workspace);
+#define SMLVM_FUSED_PAT(G)                                                                                  \
+    if (vec) hipLaunchKernelGGL((support_compact_fused_kernel<G, true, false, true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws, support_mask, pat_dwords); \
+    else hipLaunchKernelGGL((support_compact_fused_kernel<G, false, false, true>), dim3(grid), dim3(64 * kFusedWaves), 0, st, p, support_cols, support_vals, row_offsets, rows, cols, vals, n_cap, R, K, ws, support_mask, pat_dwords)
+    if (cap == 16) { SMLVM_FUSED_PAT(4); }
+    else if (cap == 64) { SMLVM_FUSED_PAT(16); }
+    else { SMLVM_FUSED_PAT(8); }
+#undef SMLVM_FUSED_PAT
     return check_launch();
 }
 

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libsparsemarg_hip.so")
 _lib = None
 
 ABI_SYMBOLS = [
-    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error", "smlvm_graph_memsets_to_kernels", "smlvm_support_segment_sum",
+    "smlvm_abi_version", "smlvm_error_string", "smlvm_last_hip_error", "smlvm_graph_memsets_to_kernels", "smlvm_support_segment_sum", "smlvm_support_compact_fused_masks",
     "smlvm_sparsemax_fwd", "smlvm_sparsemax_bwd", "smlvm_sparsemax_fwd_cols",
     "smlvm_sparsemax_bwd_cols", "smlvm_entropy", "smlvm_entmax15_fwd", "smlvm_entmax15_bwd",
     "smlvm_entmax15_fwd_lists", "smlvm_entmax15_bwd_lists",
@@ -329,7 +329,7 @@ FUSED_SMALL = 1 << 22       # R * K up to which the bound is simply R * K
 
 
 def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=True, want_cols=True,
-                          want_vals=True, n_cap=None, host_offsets=False, static=False):
+                          want_vals=True, n_cap=None, host_offsets=False, static=False, support_mask=None):
     """Count + offsets + compaction in ONE launch (smlvm_support_compact_fused) and one host sync
     (N).  The outputs are sized by an upper bound on N -- R * cap when the rows have lists, R * K
     for small matrices -- and returned as views of length N; should N exceed the bound (rows
@@ -338,6 +338,9 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     host_offsets=True appends the offsets as a host numpy array, read back in the SAME transfer as
     N (the callers that need per-row counts on the host -- SparseMAPWrapper's `support` / `idxs`
     lists -- then pay one device-to-host copy per step instead of two).
+    support_mask: the same forward's 16-bit-per-lane patterns (`functional.support_mask_of(p)`: only
+    when the forward wrote them): rows without a list are counted from those instead of from p
+    (smlvm_support_compact_fused_masks).
     static=True: no host sync at all and shapes that do not depend on the data (what a step captured
     in a HIP graph needs, lvmhelpers/graphs.py): the outputs keep their full length n_cap (default
     R * K, which cannot overflow), the entries behind the N real ones are (row 0, col 0, val 0.0),
@@ -378,11 +381,22 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
     rows = alloc(n_cap, dtype=torch.int32, device=dev) if want_rows else None
     cols = alloc(n_cap, dtype=torch.int32, device=dev) if want_cols else None
     vals = alloc(n_cap, dtype=torch.float32, device=dev) if want_vals else None
+    use_masks = (support_mask is not None and support_cols is not None and 32 < K <= 1024 and K % 4 == 0)
+    if use_masks:
+        support_mask = _need_gpu(support_mask, torch.int32, "support_mask")
+        if support_mask.numel() * 4 < lib().smlvm_sparsemax_support_mask_bytes(_i64(R), _i32(K)):
+            raise ValueError("support mask too small for this shape")
     with _on(dev):
-        _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
-                                                 _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
-                                                 _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
-                                                 _stream()), "smlvm_support_compact_fused")
+        if use_masks:
+            _check(lib().smlvm_support_compact_fused_masks(
+                _p(p), _p(support_cols), _p(support_vals), _i32(cap), _p(support_mask), _p(off), _p(rows),
+                _p(cols), _p(vals), _i64(n_cap), _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
+                _stream()), "smlvm_support_compact_fused_masks")
+        else:
+            _check(lib().smlvm_support_compact_fused(_p(p), _p(support_cols), _p(support_vals), _i32(cap),
+                                                     _p(off), _p(rows), _p(cols), _p(vals), _i64(n_cap),
+                                                     _i64(R), _i32(K), _p(ws), ctypes.c_size_t(nbytes),
+                                                     _stream()), "smlvm_support_compact_fused")
     if static:
         n_total = ws[2:3].clone()
         if n_cap < R * K:
@@ -407,7 +421,7 @@ def support_compact_fused(p, support_cols=None, support_vals=None, want_rows=Tru
 
 
 def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True, support_cols=None,
-                    row_offsets=None, total=None, support_vals=None, fused=None):
+                    row_offsets=None, total=None, support_vals=None, fused=None, support_mask=None):
     """Row-major (rows, cols, vals) lists of the positive entries of p [R,K] plus row_offsets.
 
     support_cols: the forward's support lists for this very p (`sparsemax_fwd(..., want_cols=True)`,
@@ -422,7 +436,8 @@ def support_compact(p, nnz=None, want_rows=True, want_cols=True, want_vals=True,
     R, K = p.shape
     if row_offsets is None and nnz is None and fused is not False:
         # the single-pass form (one launch, one host sync) whenever an upper bound on N is affordable
-        out = support_compact_fused(p, support_cols, support_vals, want_rows, want_cols, want_vals)
+        out = support_compact_fused(p, support_cols, support_vals, want_rows, want_cols, want_vals,
+                                    support_mask=support_mask)
         if out is not None:
             return out
     cap = 0

@@ -4,21 +4,33 @@ import torch
 from . import _native
 
 
+def _patterns_written(x, p, mask):
+    """Did this forward call leave every row's 16-bit-per-lane pattern in `mask`?  Only the vector
+    path of the 16-register tiles does (32 < K <= 1024, K % 4 == 0, x and p 16-byte aligned); the
+    pattern-fed compaction must not be handed a buffer that was never filled."""
+    K = x.shape[-1]
+    return (mask is not None and 32 < K <= 1024 and K % 4 == 0
+            and x.data_ptr() % 16 == 0 and p.data_ptr() % 16 == 0)
+
+
 class _Sparsemax(torch.autograd.Function):
     """Row-wise sparsemax over the last dim (replaces entmax.sparsemax; marg.py:45,51)."""
 
     @staticmethod
     def forward(ctx, x):
         shape = x.shape
-        p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(x.reshape(-1, shape[-1]), want_cols=True,
-                                                             want_mask=True)
+        x2 = x.reshape(-1, shape[-1])
+        p, supp, _, _, _, cols, mask = _native.sparsemax_fwd(x2, want_cols=True, want_mask=True)
         ctx.has_mask = mask is not None
         ctx.save_for_backward(p, supp, cols, *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(cols)
-        return p.view(shape), cols
+        patterns = mask if _patterns_written(x2, p, mask) else None
+        if patterns is not None:
+            ctx.mark_non_differentiable(patterns)
+        return p.view(shape), cols, patterns
 
     @staticmethod
-    def backward(ctx, dy, _dcols=None):
+    def backward(ctx, dy, _dcols=None, _dpatterns=None):
         p, supp, cols = ctx.saved_tensors[:3]
         mask = ctx.saved_tensors[3] if ctx.has_mask else None
         dx = _native.sparsemax_bwd_cols(dy.reshape(p.shape).contiguous(), cols, p, supp, mask)
@@ -60,10 +72,13 @@ class _SparsemaxEntropy(torch.autograd.Function):
         ctx.has_mask = mask is not None
         ctx.save_for_backward(p, supp, cols, *([mask] if mask is not None else []))
         ctx.mark_non_differentiable(supp, cols)
-        return p, ent, supp, cols
+        patterns = mask if _patterns_written(x, p, mask) else None
+        if patterns is not None:
+            ctx.mark_non_differentiable(patterns)
+        return p, ent, supp, cols, patterns
 
     @staticmethod
-    def backward(ctx, dp, dent, _dsupp, _dcols=None):
+    def backward(ctx, dp, dent, _dsupp, _dcols=None, _dpatterns=None):
         p, supp, cols = ctx.saved_tensors[:3]
         mask = ctx.saved_tensors[3] if ctx.has_mask else None
         if dp is None and dent is None:
@@ -258,9 +273,9 @@ def sparsemax(X, dim=-1):
         dim += X.dim()
     if dim != X.dim() - 1:
         return _Sparsemax.apply(X.transpose(dim, -1).contiguous())[0].transpose(dim, -1)
-    p, cols = _Sparsemax.apply(X.contiguous())
+    p, cols, patterns = _Sparsemax.apply(X.contiguous())
     if p.dim() == 2:
-        _tag_support(p, cols)
+        _tag_support(p, cols, patterns)
     return p
 
 
@@ -279,29 +294,42 @@ def entmax15(X, dim=-1):
 SUPPORT_ATTR = "_smlvm_support_cols"
 
 
-def _tag_support(p, cols):
+def _tag_support(p, cols, patterns=None):
     """Hang the forward's support lists on the probability tensor itself, so that a later
     `_native.support_compact(p.detach(), support_cols=support_cols_of(p))` does not have to scan p
     again.  The tag lives on this tensor object only (views, detach() and arithmetic drop it) and
     records the tensor's storage and version counter: an in-place change of p afterwards (masking,
-    renormalising, clamp_) makes the lists stale, and support_cols_of then returns None."""
-    setattr(p, SUPPORT_ATTR, (cols, p.data_ptr(), p._version))
+    renormalising, clamp_) makes the lists stale, and support_cols_of then returns None.
+    patterns: the forward's 16-bit-per-lane non-zero patterns, when it wrote them (rows without a
+    list are then counted from those instead of from p: `support_mask_of`)."""
+    setattr(p, SUPPORT_ATTR, (cols, p.data_ptr(), p._version, patterns))
 
 
-def support_cols_of(p):
+def _support_tag(p):
     tag = getattr(p, SUPPORT_ATTR, None)
     if tag is None:
         return None
-    cols, ptr, version = tag
+    cols, ptr, version, patterns = tag
     if p.dim() != 2 or cols.shape[0] != p.shape[0] or p.data_ptr() != ptr or p._version != version:
         return None
-    return cols
+    return cols, patterns
+
+
+def support_cols_of(p):
+    tag = _support_tag(p)
+    return None if tag is None else tag[0]
+
+
+def support_mask_of(p):
+    """The forward's patterns for `_native.support_compact(..., support_mask=...)`, or None."""
+    tag = _support_tag(p)
+    return None if tag is None else tag[1]
 
 
 def sparsemax_with_entropy(X):
     """X [B,K] -> (p [B,K], entropy [B], supp_size [B] int32)."""
-    p, ent, supp, cols = _SparsemaxEntropy.apply(X.contiguous())
-    _tag_support(p, cols)
+    p, ent, supp, cols, patterns = _SparsemaxEntropy.apply(X.contiguous())
+    _tag_support(p, cols, patterns)
     return p, ent, supp
 
 

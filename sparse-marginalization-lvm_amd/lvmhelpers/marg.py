@@ -122,13 +122,15 @@ class Marginalizer(torch.nn.Module):
         if self.static_shapes and self.training:
             n_cap = None if self.static_cap is None else batch_size * min(latent_size, int(self.static_cap))
             off, rows, cols, vals, n_total = _native.support_compact_fused(
-                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True,
+                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs),
+                support_mask=F_.support_mask_of(encoder_probs), static=True,
                 n_cap=n_cap)
             if n_cap is not None:
                 overflow = (n_total > n_cap).reshape(())
         else:
             off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
-                                                            support_cols=F_.support_cols_of(encoder_probs))
+                                                            support_cols=F_.support_cols_of(encoder_probs),
+                support_mask=F_.support_mask_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         if rows_l.numel() == 0:
             raise RuntimeError("Marginalizer: the encoder distribution has no live category")

@@ -81,10 +81,12 @@ class TopKSparsemaxMarg(torch.nn.Module):
         # (row, slot) of every p > 0, row-major == order of the reference's mask (structmarg.py:116)
         if self.static_shapes and self.training:
             off, rows, cols, vals, _ = _native.support_compact_fused(
-                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs), static=True)
+                encoder_probs.detach(), support_cols=F_.support_cols_of(encoder_probs),
+                support_mask=F_.support_mask_of(encoder_probs), static=True)
         else:
             off, rows, cols, vals = _native.support_compact(encoder_probs.detach(), want_vals=True,
-                                                            support_cols=F_.support_cols_of(encoder_probs))
+                                                            support_cols=F_.support_cols_of(encoder_probs),
+                support_mask=F_.support_mask_of(encoder_probs))
         rows_l, cols_l = rows.long(), cols.long()
         encoder_input_sel = encoder_input[rows_l]
         decoder_input_sel = decoder_input[rows_l]

@@ -114,6 +114,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.smlvm_support_scatter(null, null, null, null, i64(0), i32(4), null) == 0
     assert lib.smlvm_graph_memsets_to_kernels(null, null, null) == -1     # (no graph)
     assert lib.smlvm_support_segment_sum(null, null, null, i64(3), i64(4), null) == -1
+    assert lib.smlvm_support_compact_fused_masks(one, one, null, i32(32), null, one, null, null, null, i64(4), i64(2), i32(256), one, ctypes.c_size_t(64), null) == -1   # no mask
+    assert lib.smlvm_support_compact_fused_masks(one, one, null, i32(32), one, one, null, null, null, i64(4), i64(2), i32(255), one, ctypes.c_size_t(64), null) == -2   # K % 4 != 0
+    assert lib.smlvm_support_compact_fused_masks(one, one, null, i32(32), one, one, null, null, null, i64(4), i64(2), i32(2048), one, ctypes.c_size_t(64), null) == -2  # no patterns for K > 1024
     assert lib.smlvm_support_segment_sum(null, null, null, i64(0), i64(4), null) == 0
     assert lib.smlvm_support_segment_sum(one, one, one, i64(70000), i64(4), null) == -2     # R > 65535
     assert lib.smlvm_sparsemax_fwd_lists(one, one, one, null, null, null, one, one, i32(32), null, i64(3), i32(8192), null) == -2

@@ -417,3 +417,48 @@ def test_segment_sum_is_the_gather_backward(dev, oracle_mod, R, inner, dens):
     t2 = table.detach().clone().requires_grad_(True)
     (t2.index_select(0, rows_t) * w).sum().backward()
     assert float((table.grad - t2.grad).abs().max()) <= 1e-5 * max(1.0, float(t2.grad.abs().max()))
+
+
+@pytest.mark.parametrize("R,K,sigma", [(700, 256, 0.05), (300, 40, 0.02), (513, 128, 0.05), (200, 512, 0.03),
+                                       (90, 1000, 0.02), (64, 1024, 0.05), (1000, 256, 1.0), (257, 100, 0.3)])
+def test_fused_compaction_counts_unlisted_rows_from_the_patterns(dev, oracle_mod, R, K, sigma):
+    """smlvm_support_compact_fused_masks: rows whose list overflowed are counted from the forward's
+    16-bit-per-lane patterns instead of from p -- same offsets / rows / cols / vals as the oracle,
+    for every tile shape that writes patterns, ragged R, listed and unlisted rows side by side."""
+    from lvmhelpers import _native, functional as F_
+    rng = np.random.default_rng(R + K)
+    x = (sigma * rng.standard_normal((R, K))).astype(np.float32)
+    x[::7] *= 40.0                                        # some rows with short supports (listed)
+    x[3] = 0.5                                            # an all-equal row (K non-zeros)
+    xt = torch.from_numpy(x).to(dev)
+    out = _native.sparsemax_fwd(xt, want_cols=True, want_mask=True, want_vals=True)
+    p, cols, mask, vals = out[0], out[5], out[6], out[7]
+    assert mask is not None
+    unlisted = int((cols[:, 0] < -1).sum())
+    off_ref, r_ref, c_ref, v_ref = oracle_mod.support_compact(p.cpu().numpy())
+    for vl in (None, vals):
+        off, rws, cls, vs = _native.support_compact_fused(p, cols, vl, support_mask=mask)[:4]
+        assert np.array_equal(off.cpu().numpy(), off_ref)
+        assert np.array_equal(rws.cpu().numpy(), r_ref) and np.array_equal(cls.cpu().numpy(), c_ref)
+        assert np.array_equal(vs.cpu().numpy(), v_ref)
+    if sigma <= 0.05 and K >= 100:
+        assert unlisted > R // 2                          # (the case this is for: narrow logits)
+    # through the autograd function: the tag carries the patterns only when the forward wrote them
+    pt = F_.sparsemax(xt, dim=-1)
+    assert F_.support_mask_of(pt) is not None
+    off, rws, cls, vs = _native.support_compact(pt.detach(), support_cols=F_.support_cols_of(pt),
+                                                support_mask=F_.support_mask_of(pt))
+    assert np.array_equal(off.cpu().numpy(), off_ref) and np.array_equal(cls.cpu().numpy(), c_ref)
+
+
+def test_patterns_are_not_offered_when_the_forward_did_not_write_them(dev):
+    from lvmhelpers import functional as F_
+    g = torch.Generator(device=dev).manual_seed(0)
+    base = torch.randn(50 * 256 + 1, device=dev, generator=g)
+    x_unaligned = base[1:].view(50, 256)                  # 4-byte aligned rows: the scalar path
+    assert x_unaligned.data_ptr() % 16 != 0
+    assert F_.support_mask_of(F_.sparsemax(x_unaligned, dim=-1)) is None
+    assert F_.support_mask_of(F_.sparsemax(torch.randn(50, 255, device=dev), dim=-1)) is None   # K % 4 != 0
+    assert F_.support_mask_of(F_.sparsemax(torch.randn(50, 2048, device=dev), dim=-1)) is None  # bitmaps, not patterns
+    assert F_.support_mask_of(F_.sparsemax(torch.randn(50, 10, device=dev), dim=-1)) is None    # no mask buffer
+    assert F_.support_mask_of(F_.sparsemax(torch.randn(50, 256, device=dev), dim=-1)) is not None
