@@ -88,13 +88,14 @@ def sparsemax_trial(rng, trial):
               f"max err {np.abs(dx_cols - dx_ref).max():.3e}", flush=True)
     # compaction fed by the lists == compaction by scanning p == oracle
     off_ref, r_ref, c_ref, v_ref = oracle.support_compact(p_ref)
-    for lists in (None, cols):
-        off, rws, cls, vals = _native.support_compact(p, want_vals=True, support_cols=lists)
+    patterns = mask if (mask is not None and 32 < K <= 1024 and K % 4 == 0 and xt.data_ptr() % 16 == 0) else None
+    for lists, pat in ((None, None), (cols, None)) + (((cols, patterns),) if patterns is not None else ()):
+        off, rws, cls, vals = _native.support_compact(p, want_vals=True, support_cols=lists, support_mask=pat)
         if not (np.array_equal(rws.cpu().numpy(), r_ref) and np.array_equal(cls.cpu().numpy(), c_ref)
                 and np.array_equal(vals.cpu().numpy(), v_ref) and np.array_equal(off.cpu().numpy(), off_ref)):
             bad += 1
-            print(f"MISMATCH compaction ({'lists' if lists is not None else 'scan'}): trial {trial} R {R} K {K} "
-                  f"kind/sigma {tag}", flush=True)
+            print(f"MISMATCH compaction ({'patterns' if pat is not None else 'lists' if lists is not None else 'scan'}): "
+                  f"trial {trial} R {R} K {K} kind/sigma {tag}", flush=True)
 
 
 def sparsemap_trial(rng, trial):
